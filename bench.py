@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on MI355X.  Contract: `python bench.py --gpus N --steps K --warmup W`
+(N > 1: launched by torch.distributed.run, one rank per GPU) prints ONE JSON line on rank 0.
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
+  ViT-B/16 image encoder, synthetic 224x224x3 fp32 images, batch 256 per GPU, bf16 MFMA.
+One step = `encode_image` of the rank's 256 images (L2-normalised, reference
+models/model_wrapper.py:40-41) -> all-gather of the embeddings over RCCL (identity at N = 1) ->
+65-class cosine logits (model_wrapper.py:79,83) against text features computed ONCE before the timed
+region by the HIP text tower (they do not depend on the images).  value = images embedded per
+second by the whole job (weak scaling: 256 images per GPU).
+
+Extra objects on the same line:
+  roofline      dominant kernel = the bf16 MFMA GEMM (QKV / out-proj / c_fc+GELU / c_proj launches):
+                algorithmic FLOPs per launch / mean launch duration from HIP events recorded on the
+                launch stream inside the timed region, against the 2.5 PFLOP/s dense bf16 peak.
+  cpu_baseline  the CPU fp32 oracle (oracle/clip_ref.py, a port: open_clip is absent) on a bounded
+                sample of the same workload, rank 0, N = 1 only.
+  full_forward  FullModel.forward at configs[2] (image + text towers, 65 classes, 16 context tokens,
+                attention-map write-back on): logits/s, measured after the timed region.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def gemm_flops_per_image(cfg):
+    v = cfg.vision
+    n, d, f = cfg.n_tokens, v.width, v.mlp
+    per_layer = {"gemm_qkv": 2 * n * d * 3 * d, "gemm_out_proj": 2 * n * d * d, "gemm_fc_gelu": 2 * n * d * f,
+                 "gemm_proj": 2 * n * f * d}
+    return {k: val * v.layers for k, val in per_layer.items()}
+
+
+def encoder_flops_per_image(cfg):
+    """35.127 GFLOP per ViT-B/16 image (blocks + patch embed + projection)."""
+    v = cfg.vision
+    n, d, f, hd = cfg.n_tokens, v.width, v.mlp, 64
+    block = 2 * n * d * 3 * d + 2 * n * d * d + 2 * 2 * n * d * f + v.heads * (2 * 2 * n * n * hd)
+    patch = 2 * (n - 1) * (3 * cfg.patch * cfg.patch) * d
+    return v.layers * block + patch + 2 * d * cfg.embed_dim
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--model", default="ViT-B-16")
+    ap.add_argument("--classes", type=int, default=65)
+    ap.add_argument("--prompt-len", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-forward", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import tap_clip_amd
+    from tap_clip_amd import configs, engine, synth
+    from tap_clip_amd.dist import all_gather_rows
+    from tap_clip_amd.models import CLIPWrapper, FullModel
+
+    cfg = configs.get_config(args.model)
+    sd = synth.make_state_dict(cfg, seed=2)
+    clip = CLIPWrapper(args.model, None, str(dev), precision="bf16", attn_semantics="intended", state_dict=sd)
+    names = [f"class_{i}" for i in range(args.classes)]
+    model = FullModel(names, clip, prompt_len=args.prompt_len, class_specific=True, gather_images=world > 1).eval()
+    with torch.no_grad():  # seeded context (the reference draws torch.randn; any N(0,1) sample is the same workload)
+        ctx = synth.make_prompts(args.classes, args.prompt_len, cfg, seed=1)[0]
+        for i, c in enumerate(names):
+            model.prompt_learner.context_bank[c].copy_(ctx[i])
+    images = synth.make_images(args.batch, cfg, seed=100 + rank).to(dev)  # resident in HBM before timing
+    vision = clip._vision
+    scale = float(model.logit_scale.detach().exp())
+    with torch.no_grad():
+        text_feat = model.text_features()  # once, outside the timed region (image independent)
+
+    def step():
+        emb = vision.encode_image(images, normalize=True)
+        emb = all_gather_rows(emb)
+        return engine.logits(emb, text_feat, scale)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    events = not args.no_kernel_events
+    sync_all()
+    vision.profile(events)
+    vision.profile_read()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    prof = vision.profile_read() if events else None
+    vision.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert out.shape == (args.batch * world, args.classes) and bool(torch.isfinite(out).all())
+
+    total_images = args.batch * world * args.steps
+    value = total_images / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+    enc_flops = encoder_flops_per_image(cfg)
+    result = {
+        "metric": "image_embeddings_per_sec", "value": round(value, 1), "unit": "img/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: {args.model} image encoder, synthetic {cfg.image_size}x{cfg.image_size}x3, "
+                               f"batch {args.batch}/GPU, + all-gather of embeddings and {args.classes}-class logits",
+                   "batch_per_gpu": args.batch, "global_batch": args.batch * world, "tokens_per_image": cfg.n_tokens,
+                   "classes": args.classes, "parallelism": f"dp{world}", "weights": "seeded random (no checkpoint offline)"},
+        "logits_per_sec": round(value * args.classes, 1),
+        "encoder_mfma_frac": round(enc_flops * args.batch * world * args.steps / elapsed / (PEAK_BF16_TFLOPS * 1e12 * world), 4),
+        "encoder_gflop_per_image": round(enc_flops / 1e9, 3),
+    }
+
+    if prof is not None:
+        gf = gemm_flops_per_image(cfg)
+        kern = {}
+        g_ms = g_fl = 0.0
+        g_n = 0
+        for k, (ms, n) in prof.items():
+            if n == 0:
+                continue
+            e = {"ms_per_step": round(ms / args.steps, 4), "launches_per_step": n / args.steps, "avg_us": round(1e3 * ms / n, 2)}
+            if k in gf:
+                fl = gf[k] * args.batch * args.steps
+                e["tflops"] = round(fl / (ms * 1e-3) / 1e12, 1)
+                g_ms += ms
+                g_fl += fl
+                g_n += n
+            kern[k] = e
+        achieved = g_fl / (g_ms * 1e-3) / 1e12
+        result["roofline"] = {
+            "kernel": "gemm_kernel<EPI,false> (bf16 MFMA 16x16x32, 128x128x64 tile): QKV + out_proj + c_fc/GELU + c_proj launches",
+            "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "flops_per_launch": round(g_fl / g_n), "avg_launch_us": round(1e3 * g_ms / g_n, 2), "launches_per_step": g_n / args.steps,
+        }
+        ln = prof.get("layernorm")
+        if ln and ln[1]:
+            rows = args.batch * cfg.n_tokens
+            ln_bytes = (cfg.vision.layers * 2) * rows * cfg.vision.width * (4 + 2) + rows * cfg.vision.width * 8
+            result["layernorm_hbm"] = {"achieved_GBps": round(ln_bytes * args.steps / (ln[0] * 1e-3) / 1e9, 1), "peak_GBps": HBM_PEAK_GBS,
+                                       "bytes_per_step": ln_bytes}
+        result["kernels"] = kern
+
+    if rank == 0 and world == 1 and not args.no_full_forward:
+        with torch.no_grad():
+            for _ in range(2):
+                model(images)
+            torch.cuda.synchronize(dev)
+            n_it = max(3, args.steps // 4)
+            t1 = time.perf_counter()
+            for _ in range(n_it):
+                lg = model(images)["logits"]
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t1) / n_it
+        if True:
+            result["full_forward"] = {"workload": f"BASELINE configs[2]: image+text towers, {args.classes} classes, P={args.prompt_len}, "
+                                                  "attention-map write-back on, batch %d" % args.batch,
+                                      "ms_per_forward": round(1e3 * dt, 3), "logits_per_sec": round(args.batch * args.classes / dt, 1),
+                                      "images_per_sec": round(args.batch / dt, 1)}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import clip_ref  # the CPU port, timed as the baseline only
+
+        ncpu = os.cpu_count() or 1
+        torch.set_num_threads(ncpu)
+        sample = images[:32].cpu()
+        sd_v = {k: v for k, v in sd.items() if k.startswith("visual.")}
+        with torch.no_grad():
+            clip_ref.encode_image(sample[:8], sd_v, clip_ref.CONFIGS[args.model])  # warm-up
+            times = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                clip_ref.encode_image(sample, sd_v, clip_ref.CONFIGS[args.model])
+                times.append(time.perf_counter() - t1)
+        med = sorted(times)[1]
+        result["cpu_baseline"] = {"value": round(32 / med, 2), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
+                                  "sample": f"oracle/clip_ref.py encode_image fp32, {args.model}, batch 32 (of the 256), median of 3 after 1 warm-up"}
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

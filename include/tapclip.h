@@ -1,0 +1,177 @@
+/*
+ * tapclip.h -- C ABI of the MI355X (gfx950) CLIP dual-encoder hot path.
+ *
+ * This is the drop-in boundary for the ONE path of 3300786/TAP-CLIP that this
+ * project accelerates: `FullModel.forward` (reference models/model_wrapper.py:28-100)
+ * -> `CLIPWrapper.encode_image` / `clip.model.transformer` (reference
+ * models/clip_wrapper.py:46-51, models/model_wrapper.py:58,72) -> the open_clip
+ * towers.  The reference is pure Python on top of `open_clip`; the binding a
+ * maintainer adds is a ctypes stub (shown in INTEGRATION.md, shipped in
+ * tap-clip_amd/_lib.py).  Every entry point below names the reference
+ * interface it replaces.
+ *
+ * Conventions
+ *  - plain C: raw DEVICE pointers, sizes and a HIP stream; no torch types.
+ *  - all user-visible tensors are caller-owned, fp32, contiguous, row-major.
+ *    The library never allocates or frees them.  Weights are copied+packed
+ *    (bf16 hi/lo) into memory owned by the opaque tower handle; scratch is a
+ *    caller-provided workspace (size from tapclip_tower_workspace_bytes).
+ *  - every call is asynchronous w.r.t. the host and ordered on `stream`
+ *    (pass torch's current stream).  No internal host threads.  A handle is
+ *    NOT thread-safe (the reference's CLIPWrapper is not re-entrant either:
+ *    `attention_maps` is shared mutable state, clip_wrapper.py:23,42-44).
+ *  - return value: 0 = TAPCLIP_OK, negative = error; the message is in a
+ *    thread-local buffer read by tapclip_last_error().  No exception crosses
+ *    this boundary (the Python shim raises RuntimeError / ValueError).
+ */
+#ifndef TAPCLIP_H
+#define TAPCLIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TAPCLIP_ABI_VERSION 1
+
+enum {
+  TAPCLIP_OK = 0,
+  TAPCLIP_EINVAL = -1,       /* bad argument / unsupported shape          */
+  TAPCLIP_ENOMEM = -2,       /* device allocation for packed weights failed */
+  TAPCLIP_EHIP = -3,         /* a HIP runtime call or launch failed       */
+  TAPCLIP_ESTATE = -4,       /* weights missing / handle not ready        */
+  TAPCLIP_EWORKSPACE = -5    /* workspace too small                       */
+};
+
+enum { TAPCLIP_TOWER_VISION = 0, TAPCLIP_TOWER_TEXT = 1 };
+enum { TAPCLIP_ACT_GELU_ERF = 0, TAPCLIP_ACT_QUICK_GELU = 1 };
+/* arithmetic of the MFMA GEMMs / attention:
+ *   BF16   : operands rounded to bf16, fp32 accumulate (fast path, benchmarked)
+ *   BF16X3 : each operand split hi+lo bf16, 3 MFMA products (a_hi*b_hi + a_lo*b_hi
+ *            + a_hi*b_lo), ~2^-16 relative: the parity mode vs the fp32 reference */
+enum { TAPCLIP_PREC_BF16 = 0, TAPCLIP_PREC_BF16X3 = 1 };
+
+typedef struct tapclip_tower tapclip_tower_t; /* opaque */
+typedef void* tapclip_stream_t;               /* hipStream_t */
+
+typedef struct tapclip_tower_cfg {
+  int32_t kind;       /* TAPCLIP_TOWER_*                                       */
+  int32_t width;      /* d: 768 (ViT-B), 512 (text B), multiple of 128         */
+  int32_t layers;
+  int32_t heads;      /* width / heads must be 64                               */
+  int32_t mlp_dim;    /* 4 * width                                             */
+  int32_t embed_dim;  /* E: output projection width (512)                      */
+  int32_t image_size; /* vision: 224                                           */
+  int32_t patch;      /* vision: 16 / 32                                       */
+  int32_t ctx_len;    /* text: positional table length (77)                    */
+  int32_t vocab;      /* text: token-embedding rows (49408)                    */
+  int32_t act;        /* TAPCLIP_ACT_*                                         */
+  int32_t precision;  /* TAPCLIP_PREC_*                                        */
+} tapclip_tower_cfg;
+
+/* ---- handle lifetime: replaces open_clip.create_model_and_transforms +
+ * load_state_dict + .to(device).eval() in CLIPWrapper.__init__
+ * (reference models/clip_wrapper.py:10-20). ---------------------------------- */
+int tapclip_tower_create(const tapclip_tower_cfg* cfg, tapclip_tower_t** out);
+void tapclip_tower_destroy(tapclip_tower_t* tower);
+
+/* Copy + pack one state-dict tensor (fp32, device memory, open_clip key name with
+ * the tower prefix stripped: "conv1.weight", "resblocks.3.attn.in_proj_weight",
+ * "ln_post.weight", "proj", "text_projection", "token_embedding.weight", ...).
+ * Replaces `self.model.load_state_dict(state_dict, strict=True)`
+ * (reference models/clip_wrapper.py:14-15).  Unknown keys -> TAPCLIP_EINVAL. */
+int tapclip_tower_load_weight(tapclip_tower_t* tower, const char* key, const float* dev_ptr,
+                              const int64_t* shape, int32_t ndim, tapclip_stream_t stream);
+/* 0 when every required tensor has been loaded (strict=True semantics). */
+int tapclip_tower_ready(const tapclip_tower_t* tower);
+
+/* Scratch bytes needed for `rows` = n_sequences * tokens_per_sequence rows. */
+size_t tapclip_tower_workspace_bytes(const tapclip_tower_t* tower, int64_t n_seq, int32_t tokens);
+
+/* ---- `CLIPWrapper.encode_image(image_tensor)` (reference models/clip_wrapper.py:46-47):
+ * images [B,3,S,S] fp32 NCHW -> out [B,E] fp32.  normalize != 0 fuses the
+ * `image_feat / image_feat.norm(dim=-1, keepdim=True)` of model_wrapper.py:41. */
+int tapclip_encode_image(tapclip_tower_t* vision, const float* images, int32_t batch, float* out,
+                         int32_t normalize, void* workspace, size_t workspace_bytes,
+                         tapclip_stream_t stream);
+
+/* ---- `clip.model.transformer(x)` as FullModel drives it (reference
+ * models/model_wrapper.py:58,72): x [n,T,D] fp32 -> out_hidden [n,T,D] fp32, no
+ * positional embedding, no ln_final; causal != 0 adds open_clip's causal mask
+ * (the `encode_text` path, clip_wrapper.py:49-51).
+ * Optional write-back of the LAST block's attention, i.e. what the forward hook of
+ * clip_wrapper.py:29-40 is documented to capture:
+ *   attn_heads [n,H,T,T] fp32 softmax probabilities per head      (nullable)
+ *   attn_mean  [n,T,T]   fp32 head mean                            (nullable)
+ *   attn_out   [n,T,D]   fp32 output of the attention module (post out_proj, pre
+ *              residual): what the hook LITERALLY captures (`output[0]`)  (nullable) */
+int tapclip_text_forward(tapclip_tower_t* text, const float* x, int32_t n_seq, int32_t tokens,
+                         int32_t causal, float* out_hidden, float* attn_heads, float* attn_mean,
+                         float* attn_out, void* workspace, size_t workspace_bytes,
+                         tapclip_stream_t stream);
+
+/* ---- token gather + projection + L2 norm (reference models/model_wrapper.py:73-75:
+ * `text_feat[arange(B), -1, :] @ text_projection`, `/ norm`).  index == NULL picks
+ * token T-1; otherwise index[i] (int64, device) is the token of sequence i (EOT pool of
+ * encode_text).  apply_ln_final != 0 applies ln_final to the picked row first. */
+int tapclip_text_pool_project(tapclip_tower_t* text, const float* hidden, int32_t n_seq,
+                              int32_t tokens, const int64_t* index, int32_t apply_ln_final,
+                              int32_t normalize, float* out, tapclip_stream_t stream);
+
+/* ---- token_embedding(tokens) + positional_embedding (open_clip encode_text prologue;
+ * reference models/prompt_learner.py:32-33 calls token_embedding alone: add_pos = 0).
+ * tokens [n,L] int64 -> out [n,L,D] fp32. */
+int tapclip_embed_tokens(tapclip_tower_t* text, const int64_t* tokens, int32_t n_seq, int32_t len,
+                         int32_t add_pos, float* out, tapclip_stream_t stream);
+
+/* ---- `AttributionMonitor.forward` (reference models/attribution_monitor.py:17-36):
+ * attn_map [n,T,T2] -> out [n,P] = softmax_p(attn_map[:, :P, T-1]) (normalize != 0)
+ * or the raw column.  T2 is the trailing dim (== T for a real map; the literal hook
+ * hands over [n,1,D]: T = 1, T2 = D). */
+int tapclip_attribution(const float* attn_map, int32_t n, int32_t T, int32_t T2, int32_t P,
+                        int32_t normalize, float* out, tapclip_stream_t stream);
+
+/* ---- `PromptAdjustor('scale')` + the two torch.cat of reference
+ * models/prompt_adjustor.py:35-36 and models/model_wrapper.py:51,68-69:
+ * out[n, :P] = ctx[n] * attribution[n,:,None] (attribution NULL -> plain copy),
+ * out[n, P:] = tok[n].   ctx [n,P,D], tok [n,L,D], out [n,P+L,D].
+ * attr_cols = trailing size of attribution (P, or 1 for the literal hook: broadcast). */
+int tapclip_build_prompts(const float* ctx, const float* tok, const float* attribution,
+                          int32_t attr_cols, int32_t n, int32_t P, int32_t L, int32_t D, float* out,
+                          tapclip_stream_t stream);
+
+/* ---- cosine logits (reference models/model_wrapper.py:79,83):
+ * out[b,c] = scale * sum_e img[b,e] * txt[c,e]; img, txt already L2-normalised. */
+int tapclip_logits(const float* img, const float* txt, float scale, int32_t B, int32_t C, int32_t E,
+                   float* out, tapclip_stream_t stream);
+
+/* ---- unit entry points for the per-kernel parity tests and roofline micro-benches
+ * (SURVEY.md section 2.1 K2 and K3/K5/K6/K7).  Row-major fp32 in/out. -------- */
+/* y = LayerNorm(x) * gamma + beta, eps 1e-5; rows x d. */
+int tapclip_layernorm_f32(const float* x, const float* gamma, const float* beta, int64_t rows,
+                          int32_t d, float* y, tapclip_stream_t stream);
+/* C[M,N] = A[M,K] @ W[N,K]^T + bias[N] (bias nullable); precision = TAPCLIP_PREC_*.
+ * scratch must hold 2*(M*K + N*K + ...) bf16: use tapclip_gemm_scratch_bytes. */
+size_t tapclip_gemm_scratch_bytes(int64_t M, int32_t N, int32_t K);
+int tapclip_gemm_f32(const float* A, const float* W, const float* bias, int64_t M, int32_t N,
+                     int32_t K, int32_t precision, float* C, void* scratch, size_t scratch_bytes,
+                     tapclip_stream_t stream);
+
+/* ---- per-stage timing (HIP events on `stream`) for bench.py's roofline object.
+ * When enabled, tapclip_encode_image records events around each kernel family;
+ * tapclip_profile_read (after a stream sync) returns accumulated ms and launch counts.
+ * slots: 0 patch-embed, 1 layernorm, 2 gemm_qkv, 3 attention, 4 gemm_out_proj,
+ *        5 gemm_fc_gelu, 6 gemm_proj, 7 pool_proj. */
+#define TAPCLIP_PROFILE_SLOTS 8
+int tapclip_profile_enable(tapclip_tower_t* tower, int32_t on);
+int tapclip_profile_read(tapclip_tower_t* tower, float* ms_out, int64_t* launches_out);
+
+const char* tapclip_last_error(void);
+int tapclip_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAPCLIP_H */

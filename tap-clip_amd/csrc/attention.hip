@@ -1,0 +1,269 @@
+// Multi-head self-attention core for gfx950 (head dim 64, T <= 256 keys): softmax(Q K^T) V per
+// (sequence, head), with optional write-back of the softmax probabilities.
+//
+// Replaces the scaled-dot-product step inside nn.MultiheadAttention that open_clip's
+// ResidualAttentionBlock runs, and produces the per-head attention map
+// that the reference's forward hook is documented to capture (reference models/clip_wrapper.py:29-40;
+// K4').  1/sqrt(64) is folded into Wq/bq at weight-pack time.
+//
+// One 256-thread workgroup per (sequence, head); the head's whole K and V (<= 256 x 64 bf16) sit in
+// LDS; each wave owns 16-query tiles.  All products are issued "transposed" so softmax is lane-local:
+//   S^T[key, q] = K . Q^T   (A = K rows from LDS by ds_read_b128, B = Q rows straight from global)
+//     -> lane (r = lane & 15, g = lane >> 4) holds, for query r, keys 16*kt + 4*g + e (e = 0..3) of
+//        every key tile kt: a query's row is spread over only 4 lanes (xor 16, xor 32 reductions).
+//   O^T[d, q] = V^T . P^T   (A = V^T via ds_read_b64_tr_b16 transposed LDS reads, B = P^T = the S^T
+//        registers themselves, packed to bf16: element jj of k-step s2 is key 16*(2*s2 + (jj>>2)) + 4*g
+//        + (jj&3); the V^T fragment is read with the same key order)
+//     -> lane holds 4 consecutive d of one query: 8-byte stores.
+// bf16x3 (SPLIT): K, V, Q and P are hi/lo pairs and every product is three MFMAs.
+#include "common.h"
+#include "kernels.h"
+
+namespace tapclip {
+namespace {
+
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+
+__device__ __forceinline__ bf16x8_t tr_pair(const uint8_t* base0, const uint8_t* base1) {
+  // two transposed 4-key x 16-d blocks -> one 8-element (k = 8 keys) MFMA fragment
+  s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(base0));
+  s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(base1));
+  s16x8_t v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int NKT, bool SPLIT>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+  constexpr int KEYS = NKT * 16;
+  constexpr int TILE = KEYS * 128;  // bytes of one [KEYS][64] bf16 image
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* Kh = smem;                  // swizzled rows (b128 reads)
+  uint8_t* Vh = smem + TILE;           // plain rows (transposed reads)
+  uint8_t* Kl = smem + 2 * TILE;       // SPLIT only
+  uint8_t* Vl = smem + 3 * TILE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int T = a.T, D = a.D;
+  const int seq = blockIdx.x / a.H, head = blockIdx.x - seq * a.H;
+  const int64_t row0 = (int64_t)seq * T;
+  const int64_t ld = 3 * (int64_t)D;
+  const int qcol = head * 64, kcol = D + head * 64, vcol = 2 * D + head * 64;
+
+  // ---- stage K (swizzled) and V (plain) of this head into LDS; rows >= T are zero
+  for (int c = tid; c < KEYS * 8; c += 256) {
+    const int key = c >> 3, kc = c & 7;
+    uint4 kv = make_uint4(0, 0, 0, 0), vv = kv, kvl = kv, vvl = kv;
+    if (key < T) {
+      const int64_t base = (row0 + key) * ld + kc * 8;
+      kv = *reinterpret_cast<const uint4*>(a.qkv_hi + base + kcol);
+      vv = *reinterpret_cast<const uint4*>(a.qkv_hi + base + vcol);
+      if (SPLIT) {
+        kvl = *reinterpret_cast<const uint4*>(a.qkv_lo + base + kcol);
+        vvl = *reinterpret_cast<const uint4*>(a.qkv_lo + base + vcol);
+      }
+    }
+    const int ko = key * 128 + ((kc ^ (key & 7)) << 4);
+    const int vo = key * 128 + (kc << 4);
+    *reinterpret_cast<uint4*>(Kh + ko) = kv;
+    *reinterpret_cast<uint4*>(Vh + vo) = vv;
+    if (SPLIT) {
+      *reinterpret_cast<uint4*>(Kl + ko) = kvl;
+      *reinterpret_cast<uint4*>(Vl + vo) = vvl;
+    }
+  }
+  __syncthreads();
+
+  const int n_qt = (T + 15) >> 4;
+  for (int qt = wave; qt < n_qt; qt += 4) {
+    const int qi = qt * 16 + r;             // this lane's query (column of S^T)
+    const int qrow = qi < T ? qi : T - 1;   // clamp: padded queries are computed, never stored
+    // Q fragments: B[k = d = 32*s + 8*g + j][col = q]
+    bf16x8_t qh[2], ql[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int64_t off = (row0 + qrow) * ld + qcol + 32 * s + 8 * g;
+      qh[s] = *reinterpret_cast<const bf16x8_t*>(a.qkv_hi + off);
+      if (SPLIT) ql[s] = *reinterpret_cast<const bf16x8_t*>(a.qkv_lo + off);
+    }
+
+    // ---- S^T = K . Q^T
+    f32x4_t sc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      sc[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const int key = kt * 16 + r;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int off = key * 128 + (((4 * s + g) ^ (key & 7)) << 4);
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Kh + off);
+        sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qh[s], sc[kt], 0, 0, 0);
+        if (SPLIT) {
+          const bf16x8_t kfl = *reinterpret_cast<const bf16x8_t*>(Kl + off);
+          sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfl, qh[s], sc[kt], 0, 0, 0);
+          sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, ql[s], sc[kt], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- mask + softmax over keys (lane-local + 2 shuffles)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int key = kt * 16 + 4 * g + e;
+        const bool dead = key >= T || (a.causal && key > qi);
+        if (dead) sc[kt][e] = -INFINITY;
+        mx = fmaxf(mx, sc[kt][e]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float p = __expf(sc[kt][e] - mx);  // exp(-inf) = 0 for masked keys
+        sc[kt][e] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sc[kt][e] *= inv;
+
+    // ---- optional probability write-back: probs[seq, head, q, key]
+    if (a.probs != nullptr && qi < T) {
+      float* prow = a.probs + (((int64_t)seq * a.H + head) * T + qi) * T;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int key = kt * 16 + 4 * g + e;
+          if (key < T) prow[key] = sc[kt][e];
+        }
+    }
+
+    // ---- O^T = V^T . P^T
+    f32x4_t oc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // transposed-read lane address: in-group index i = 4*qq + pp supplies row qq, columns 4*pp..4*pp+3
+    const int qq = r >> 2, pp = r & 3;
+#pragma unroll
+    for (int s2 = 0; s2 < NKT / 2; ++s2) {
+      bf16x8_t ph, pl;
+      {
+        bf16_t h[8], l[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const float p = sc[2 * s2 + (jj >> 2)][jj & 3];
+          if (SPLIT) split_bf(p, h[jj], l[jj]);
+          else h[jj] = f2bf(p);
+        }
+        s16x8_t hv = {(short)h[0], (short)h[1], (short)h[2], (short)h[3], (short)h[4], (short)h[5], (short)h[6], (short)h[7]};
+        ph = __builtin_bit_cast(bf16x8_t, hv);
+        if (SPLIT) {
+          s16x8_t lv = {(short)l[0], (short)l[1], (short)l[2], (short)l[3], (short)l[4], (short)l[5], (short)l[6], (short)l[7]};
+          pl = __builtin_bit_cast(bf16x8_t, lv);
+        }
+      }
+      const int key0 = 16 * (2 * s2) + 4 * g + qq;
+      const int key1 = 16 * (2 * s2 + 1) + 4 * g + qq;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int coff = (16 * dt + 4 * pp) * 2;
+        const bf16x8_t vf = tr_pair(Vh + key0 * 128 + coff, Vh + key1 * 128 + coff);
+        oc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, ph, oc[dt], 0, 0, 0);
+        if (SPLIT) {
+          const bf16x8_t vfl = tr_pair(Vl + key0 * 128 + coff, Vl + key1 * 128 + coff);
+          oc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfl, ph, oc[dt], 0, 0, 0);
+          oc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pl, oc[dt], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- store: lane holds O[q = qi][d = 16*dt + 4*g + e]
+    if (qi < T) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int64_t off = (row0 + qi) * D + head * 64 + 16 * dt + 4 * g;
+        bf16_t h[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (SPLIT) split_bf(oc[dt][e], h[e], l[e]);
+          else h[e] = f2bf(oc[dt][e]);
+        }
+        uint2 phk;
+        phk.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+        phk.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+        *reinterpret_cast<uint2*>(a.out_hi + off) = phk;
+        if (SPLIT) {
+          uint2 plk;
+          plk.x = (uint32_t)l[0] | ((uint32_t)l[1] << 16);
+          plk.y = (uint32_t)l[2] | ((uint32_t)l[3] << 16);
+          *reinterpret_cast<uint2*>(a.out_lo + off) = plk;
+        }
+      }
+    }
+  }
+}
+
+template <int NKT, bool SPLIT>
+hipError_t launch_t(const AttnArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  const int smem_bytes = NKT * 16 * 128 * (SPLIT ? 4 : 2);
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<NKT, SPLIT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_kernel<NKT, SPLIT>), dim3((unsigned)(a.n_seq * a.H)), dim3(256), smem_bytes, s, a);
+  return hipGetLastError();
+}
+
+template <bool SPLIT>
+hipError_t dispatch(const AttnArgs& a, hipStream_t s) {
+  const int nkt = ((a.T + 31) / 32) * 2;  // even number of 16-key tiles
+  switch (nkt) {
+    case 2: return launch_t<2, SPLIT>(a, s);
+    case 4: return launch_t<4, SPLIT>(a, s);
+    case 6: return launch_t<6, SPLIT>(a, s);
+    case 8: return launch_t<8, SPLIT>(a, s);
+    case 10: return launch_t<10, SPLIT>(a, s);
+    case 12: return launch_t<12, SPLIT>(a, s);
+    case 14: return launch_t<14, SPLIT>(a, s);
+    case 16: return launch_t<16, SPLIT>(a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+__global__ void head_mean_kernel(const float* __restrict__ probs, int H, int64_t tt, int64_t total, float* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t seq = i / tt, e = i - seq * tt;
+  const float* p = probs + seq * H * tt + e;
+  float s = 0.f;
+  for (int h = 0; h < H; ++h) s += p[h * tt];  // same summation order as torch .mean(dim=1) for small H
+  out[i] = s / (float)H;
+}
+
+}  // namespace
+
+hipError_t launch_attention(const AttnArgs& a, bool split, hipStream_t s) {
+  if (a.T <= 0 || a.T > 256 || a.D != a.H * 64 || a.n_seq <= 0) return hipErrorInvalidValue;
+  return split ? dispatch<true>(a, s) : dispatch<false>(a, s);
+}
+
+hipError_t launch_head_mean(const float* probs, int32_t n, int32_t H, int32_t T, float* out, hipStream_t s) {
+  const int64_t tt = (int64_t)T * T, total = (int64_t)n * tt;
+  hipLaunchKernelGGL(head_mean_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, probs, H, tt, total, out);
+  return hipGetLastError();
+}
+
+}  // namespace tapclip

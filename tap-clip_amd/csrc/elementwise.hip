@@ -1,0 +1,338 @@
+// Small HBM/latency-bound kernels around the towers: patch gather (im2col), weight packing,
+// pool + LayerNorm + projection + L2-norm, token embedding, attribution, prompt assembly, logits.
+// Reference call sites are cited per kernel.
+#include "common.h"
+#include "kernels.h"
+
+namespace tapclip {
+namespace {
+
+// ---- K1 (front half): conv1 with stride == kernel == patch is a GEMM over gathered patches.
+// patches[(b*G + py)*G + px][c*p*p + ky*p + kx] = img[b][c][py*p + ky][px*p + kx]
+// (open_clip visual.conv1, reached through reference models/clip_wrapper.py:47).
+// One thread per 8 output elements (8 consecutive kx) when p % 8 == 0: two float4 loads, one
+// 16-byte bf16 store.
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void im2col8_kernel(const float* __restrict__ img, int B, int S, int p, int Kp,
+                                                      bf16_t* hi, bf16_t* lo) {
+  const int G = S / p;
+  const int chunks_per_row = Kp / 8;
+  const int64_t total = (int64_t)B * G * G * chunks_per_row;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t prow = i / chunks_per_row;
+  const int ch = (int)(i - prow * chunks_per_row);
+  const int k = ch * 8;
+  uint4 oh = make_uint4(0, 0, 0, 0), ol = oh;
+  if (k < 3 * p * p) {
+    const int c = k / (p * p), rem = k - c * p * p;
+    const int ky = rem / p, kx = rem - ky * p;
+    const int64_t b = prow / (G * G);
+    const int pr = (int)(prow - b * G * G);
+    const int py = pr / G, px = pr - py * G;
+    const float* src = img + ((b * 3 + c) * S + (py * p + ky)) * (int64_t)S + px * p + kx;
+    const float4 v0 = *reinterpret_cast<const float4*>(src);
+    const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
+    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    bf16_t h[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (SPLIT) split_bf(v[e], h[e], l[e]);
+      else h[e] = f2bf(v[e]);
+    }
+    oh = make_uint4((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16),
+                    (uint32_t)h[4] | ((uint32_t)h[5] << 16), (uint32_t)h[6] | ((uint32_t)h[7] << 16));
+    if (SPLIT)
+      ol = make_uint4((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16),
+                      (uint32_t)l[4] | ((uint32_t)l[5] << 16), (uint32_t)l[6] | ((uint32_t)l[7] << 16));
+  }
+  *reinterpret_cast<uint4*>(hi + prow * Kp + k) = oh;
+  if (SPLIT) *reinterpret_cast<uint4*>(lo + prow * Kp + k) = ol;
+}
+
+// generic patch sizes (p % 8 != 0, e.g. 14): one thread per element
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void im2col1_kernel(const float* __restrict__ img, int B, int S, int p, int Kp,
+                                                      bf16_t* hi, bf16_t* lo) {
+  const int G = S / p;
+  const int64_t total = (int64_t)B * G * G * Kp;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t prow = i / Kp;
+  const int k = (int)(i - prow * Kp);
+  float v = 0.f;
+  if (k < 3 * p * p) {
+    const int c = k / (p * p), rem = k - c * p * p;
+    const int ky = rem / p, kx = rem - ky * p;
+    const int64_t b = prow / (G * G);
+    const int pr = (int)(prow - b * G * G);
+    const int py = pr / G, px = pr - py * G;
+    v = img[((b * 3 + c) * S + (py * p + ky)) * (int64_t)S + px * p + kx];
+  }
+  if (SPLIT) {
+    bf16_t h, l;
+    split_bf(v, h, l);
+    hi[i] = h;
+    lo[i] = l;
+  } else {
+    hi[i] = f2bf(v);
+  }
+}
+
+// x[b, 0, :] = class_embedding + positional_embedding[0]  (open_clip VisionTransformer.forward)
+__global__ void class_token_kernel(const float* __restrict__ cls, const float* __restrict__ pos, int B,
+                                   int tokens, int D, float* x) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * D) return;
+  const int64_t b = i / D;
+  const int c = (int)(i - b * D);
+  x[b * tokens * D + c] = cls[c] + pos[c];
+}
+
+// fp32 -> bf16 hi (+ lo) weight packing; rows < scale_rows are pre-multiplied by scale (1/sqrt(hd) on
+// the q rows of in_proj_weight).  dst_ld >= cols, padding zero-filled.
+template <bool SPLIT>
+__global__ void pack_kernel(const float* __restrict__ src, int64_t rows, int cols, int64_t src_ld, int dst_ld,
+                            int64_t scale_rows, float scale, bf16_t* hi, bf16_t* lo) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * dst_ld) return;
+  const int64_t rr = i / dst_ld;
+  const int c = (int)(i - rr * dst_ld);
+  float v = 0.f;
+  if (c < cols) {
+    v = src[rr * src_ld + c];
+    if (rr < scale_rows) v *= scale;
+  }
+  if (SPLIT) {
+    bf16_t h, l;
+    split_bf(v, h, l);
+    hi[i] = h;
+    lo[i] = l;
+  } else {
+    hi[i] = f2bf(v);
+  }
+}
+
+__global__ void scale_copy_kernel(const float* __restrict__ src, int64_t n, int64_t scale_n, float scale, float* dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  dst[i] = i < scale_n ? src[i] * scale : src[i];
+}
+
+// ---- K8/K9/K11: row gather -> optional LayerNorm -> @ proj[K, E] -> optional L2 normalise.
+// vision: CLS row, ln_post, visual.proj (open_clip VisionTransformer tail; reference
+// models/clip_wrapper.py:47 + models/model_wrapper.py:41).  text: token -1, text_projection, norm
+// (reference models/model_wrapper.py:73-75); encode_text: EOT row, ln_final (clip_wrapper.py:49-51).
+// One workgroup per output row; fp32 FMA throughout (0.8 MFLOP per row).
+__global__ __launch_bounds__(256) void pool_project_kernel(const float* __restrict__ src, int tokens, int K,
+                                                           const int64_t* __restrict__ index, int fixed_token,
+                                                           const float* __restrict__ ln_g,
+                                                           const float* __restrict__ ln_b,
+                                                           const float* __restrict__ proj, int E, int normalize,
+                                                           float* out) {
+  extern __shared__ float sh[];  // K floats (row) + 8 floats (reductions)
+  float* row = sh;
+  float* red = sh + K;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t n = blockIdx.x;
+  int tok = fixed_token;
+  if (index != nullptr) tok = (int)index[n];
+  if (tok < 0) tok += tokens;
+  const float* xr = src + (n * tokens + tok) * (int64_t)K;
+  for (int c = tid; c < K; c += 256) row[c] = xr[c];
+  __syncthreads();
+  if (ln_g != nullptr) {
+    float s = 0.f;
+    for (int c = tid; c < K; c += 256) s += row[c];
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)K;
+    __syncthreads();
+    float ss = 0.f;
+    for (int c = tid; c < K; c += 256) {
+      const float t = row[c] - mean;
+      ss += t * t;
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + 1e-5f);
+    __syncthreads();
+    for (int c = tid; c < K; c += 256) row[c] = (row[c] - mean) * rstd * ln_g[c] + ln_b[c];
+    __syncthreads();
+  }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};  // E <= 1024
+  for (int k = 0; k < K; ++k) {
+    const float xv = row[k];
+    const float* pr = proj + (int64_t)k * E;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = tid + 256 * j;
+      if (e < E) acc[j] = fmaf(xv, pr[e], acc[j]);
+    }
+  }
+  float scale = 1.f;
+  if (normalize) {
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (tid + 256 * j < E) ss += acc[j] * acc[j];
+    ss = wave_sum(ss);
+    if (lane == 0) red[4 + wave] = ss;
+    __syncthreads();
+    scale = 1.0f / sqrtf(red[4] + red[5] + red[6] + red[7]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = tid + 256 * j;
+    if (e < E) out[n * E + e] = acc[j] * scale;
+  }
+}
+
+// token_embedding gather (+ positional embedding): reference models/prompt_learner.py:32-33
+// (no pos) and open_clip encode_text prologue (with pos).
+__global__ void embed_tokens_kernel(const float* __restrict__ table, int vocab, const float* __restrict__ pos,
+                                    const int64_t* __restrict__ tokens, int64_t total, int L, int D, int add_pos,
+                                    float* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t t = i / D;
+  const int c = (int)(i - t * D);
+  int64_t id = tokens[t];
+  if (id < 0) id = 0;
+  if (id >= vocab) id = vocab - 1;
+  float v = table[id * D + c];
+  if (add_pos) v += pos[(t % L) * D + c];
+  out[i] = v;
+}
+
+// ---- K12a: AttributionMonitor.forward (reference models/attribution_monitor.py:17-36):
+// out[n, p] = softmax_p( amap[n, p, T-1] ), p < min(P, T) rows.  One wave per sequence.
+__global__ __launch_bounds__(64) void attribution_kernel(const float* __restrict__ amap, int T, int T2, int P,
+                                                         int normalize, float* out) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  const int rows = P < T ? P : T;  // torch slicing [:P] on a T-row map
+  const float* base = amap + (int64_t)n * T * T2;
+  float mx = -INFINITY;
+  for (int p = lane; p < rows; p += 64) mx = fmaxf(mx, base[(int64_t)p * T2 + (T - 1)]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int p = lane; p < rows; p += 64) s += expf(base[(int64_t)p * T2 + (T - 1)] - mx);
+  s = wave_sum(s);
+  for (int p = lane; p < rows; p += 64) {
+    const float v = base[(int64_t)p * T2 + (T - 1)];
+    out[(int64_t)n * rows + p] = normalize ? expf(v - mx) / s : v;
+  }
+}
+
+// ---- K12b: PromptAdjustor('scale') + the concatenations (reference models/prompt_adjustor.py:35-36,
+// models/model_wrapper.py:51,68-69; models/prompt_learner.py:62-65 when attr == nullptr)
+__global__ void build_prompts_kernel(const float* __restrict__ ctx, const float* __restrict__ tok,
+                                     const float* __restrict__ attr, int attr_cols, int P, int L, int D,
+                                     int64_t total, float* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int T = P + L;
+  const int64_t n = i / ((int64_t)T * D);
+  const int64_t rem = i - n * T * D;
+  const int t = (int)(rem / D), c = (int)(rem - (int64_t)t * D);
+  float v;
+  if (t < P) {
+    v = ctx[(n * P + t) * D + c];
+    if (attr != nullptr) v *= attr[n * attr_cols + (attr_cols == 1 ? 0 : t)];
+  } else {
+    v = tok[(n * L + (t - P)) * D + c];
+  }
+  out[i] = v;
+}
+
+// ---- K13: logits[b, c] = scale * <img[b], txt[c]> (reference models/model_wrapper.py:79,83).
+// One workgroup per image row; each wave walks classes, lanes split E.
+__global__ __launch_bounds__(256) void logits_kernel(const float* __restrict__ img, const float* __restrict__ txt,
+                                                     float scale, int C, int E, float* out) {
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* ir = img + (int64_t)b * E;
+  for (int c = wave; c < C; c += 4) {
+    const float* tr = txt + (int64_t)c * E;
+    float s = 0.f;
+    for (int e = lane; e < E; e += 64) s = fmaf(ir[e], tr[e], s);
+    s = wave_sum(s);
+    if (lane == 0) out[(int64_t)b * C + c] = scale * s;
+  }
+}
+
+inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+hipError_t launch_im2col(const float* img, int32_t B, int32_t S, int32_t p, int32_t Kp, bf16_t* hi, bf16_t* lo,
+                         hipStream_t s) {
+  const int G = S / p;
+  if (p % 8 == 0 && S % 4 == 0) {
+    const int64_t total = (int64_t)B * G * G * (Kp / 8);
+    if (lo) hipLaunchKernelGGL((im2col8_kernel<true>), dim3(blocks_for(total, 256)), dim3(256), 0, s, img, B, S, p, Kp, hi, lo);
+    else hipLaunchKernelGGL((im2col8_kernel<false>), dim3(blocks_for(total, 256)), dim3(256), 0, s, img, B, S, p, Kp, hi, lo);
+  } else {
+    const int64_t total = (int64_t)B * G * G * Kp;
+    if (lo) hipLaunchKernelGGL((im2col1_kernel<true>), dim3(blocks_for(total, 256)), dim3(256), 0, s, img, B, S, p, Kp, hi, lo);
+    else hipLaunchKernelGGL((im2col1_kernel<false>), dim3(blocks_for(total, 256)), dim3(256), 0, s, img, B, S, p, Kp, hi, lo);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_class_token(const float* cls, const float* pos, int32_t B, int32_t tokens, int32_t D, float* x,
+                              hipStream_t s) {
+  hipLaunchKernelGGL(class_token_kernel, dim3(blocks_for((int64_t)B * D, 256)), dim3(256), 0, s, cls, pos, B, tokens, D, x);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack(const float* src, int64_t rows, int32_t cols, int64_t src_ld, int32_t dst_ld,
+                       int64_t scale_rows, float scale, bf16_t* hi, bf16_t* lo, hipStream_t s) {
+  const int64_t total = rows * dst_ld;
+  if (lo) hipLaunchKernelGGL((pack_kernel<true>), dim3(blocks_for(total, 256)), dim3(256), 0, s, src, rows, cols, src_ld, dst_ld, scale_rows, scale, hi, lo);
+  else hipLaunchKernelGGL((pack_kernel<false>), dim3(blocks_for(total, 256)), dim3(256), 0, s, src, rows, cols, src_ld, dst_ld, scale_rows, scale, hi, lo);
+  return hipGetLastError();
+}
+
+hipError_t launch_scale_copy(const float* src, int64_t n, int64_t scale_n, float scale, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(scale_copy_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, src, n, scale_n, scale, dst);
+  return hipGetLastError();
+}
+
+hipError_t launch_pool_project(const float* src, int64_t n, int32_t tokens, int32_t K, const int64_t* index,
+                               int32_t fixed_token, const float* ln_g, const float* ln_b, const float* proj,
+                               int32_t E, int32_t normalize, float* out, hipStream_t s) {
+  if (E > 1024 || K > 8192) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pool_project_kernel, dim3((unsigned)n), dim3(256), (K + 8) * sizeof(float), s, src, tokens, K,
+                     index, fixed_token, ln_g, ln_b, proj, E, normalize, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_embed_tokens(const float* table, int32_t vocab, const float* pos, const int64_t* tokens, int32_t n,
+                               int32_t L, int32_t D, int32_t add_pos, float* out, hipStream_t s) {
+  const int64_t total = (int64_t)n * L * D;
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, table, vocab, pos, tokens, total, L, D, add_pos, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_attribution(const float* amap, int32_t n, int32_t T, int32_t T2, int32_t P, int32_t normalize,
+                              float* out, hipStream_t s) {
+  hipLaunchKernelGGL(attribution_kernel, dim3((unsigned)n), dim3(64), 0, s, amap, T, T2, P, normalize, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_build_prompts(const float* ctx, const float* tok, const float* attr, int32_t attr_cols, int32_t n,
+                                int32_t P, int32_t L, int32_t D, float* out, hipStream_t s) {
+  const int64_t total = (int64_t)n * (P + L) * D;
+  hipLaunchKernelGGL(build_prompts_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, ctx, tok, attr, attr_cols, P, L, D, total, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_logits(const float* img, const float* txt, float scale, int32_t B, int32_t C, int32_t E, float* out,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(logits_kernel, dim3((unsigned)B), dim3(256), 0, s, img, txt, scale, C, E, out);
+  return hipGetLastError();
+}
+
+}  // namespace tapclip

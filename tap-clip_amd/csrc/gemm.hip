@@ -1,0 +1,233 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] = A[M,K] . W[N,K]^T  with fused epilogues.
+//
+// Replaces the nn.Linear / conv1 calls that open_clip's towers execute for the reference
+// (SURVEY.md section 2.1 K1,K3,K5,K6,K7; reference call sites models/clip_wrapper.py:47,
+// models/model_wrapper.py:58,72).
+//
+// Tile: 128 (m) x 128 (n) x 64 (k) per 256-thread workgroup = 4 waves as 2(m) x 2(n); each wave owns
+// 64 x 64 = 4 x 4 tiles of v_mfma_f32_16x16x32_bf16.  Both operands are K-contiguous, so the MFMA is
+// issued "swapped" (D = Wfrag . Afrag^T): a lane then holds 4 CONSECUTIVE n for one m, i.e. 8-byte
+// (bf16) / 16-byte (fp32) vector stores and vector bias loads in the epilogue.
+// LDS image: [128 rows][64 bf16] = 128-B rows, 16-B chunk index XOR (row & 7) so the ds_read_b128
+// fragment reads of 16 different rows at one k-chunk spread over 8 slots (guide T2).
+// bf16x3 (SPLIT): the K loop runs three segments (A_hi,W_hi), (A_lo,W_hi), (A_hi,W_lo) into the same
+// accumulators.
+#include "common.h"
+#include "kernels.h"
+
+namespace tapclip {
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+
+struct Stage {
+  uint4 a[4];
+  uint4 w[4];
+};
+
+template <bool SPLIT>
+__device__ __forceinline__ void stage_load(const GemmArgs& g, int64_t m0, int n0, int kt, int KT1, int tid,
+                                           Stage& st) {
+  int seg = 0, kk = kt;
+  if (SPLIT) {
+    seg = kt / KT1;
+    kk = kt - seg * KT1;
+  }
+  const bf16_t* Ap = (SPLIT && seg == 1) ? g.A_lo : g.A_hi;
+  const bf16_t* Wp = (SPLIT && seg == 2) ? g.W_lo : g.W_hi;
+  const int k0 = kk * BK;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i;
+    const int row = c >> 3, kc = c & 7;
+    int64_t m = m0 + row;
+    if (m >= g.M) m = g.M - 1;  // clamp: rows past M are computed but never stored
+    st.a[i] = *reinterpret_cast<const uint4*>(Ap + m * g.lda + k0 + kc * 8);
+    st.w[i] = *reinterpret_cast<const uint4*>(Wp + (int64_t)(n0 + row) * g.K + k0 + kc * 8);
+  }
+}
+
+__device__ __forceinline__ void stage_write(uint8_t* bufA, uint8_t* bufW, int tid, const Stage& st) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i;
+    const int row = c >> 3, kc = c & 7;
+    const int off = row * 128 + ((kc ^ (row & 7)) << 4);
+    *reinterpret_cast<uint4*>(bufA + off) = st.a[i];
+    *reinterpret_cast<uint4*>(bufW + off) = st.w[i];
+  }
+}
+
+template <int EPI, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // [2 buffers][A | W] = 64 KiB
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware, bijective block remap (guide T1): blocks that share an XCD (same blockIdx % 8) walk a
+  // contiguous run of tiles, n fastest, so the A row-panel is re-used out of that XCD's L2.
+  const int tiles_n = g.N / BN;
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
+    bid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int64_t m0 = (int64_t)tm * BM;
+  const int n0 = tn * BN;
+
+  const int KT1 = g.K / BK;
+  const int KT = SPLIT ? 3 * KT1 : KT1;
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  Stage st;
+  stage_load<SPLIT>(g, m0, n0, 0, KT1, tid, st);
+  stage_write(smem, smem + TILE_BYTES, tid, st);
+  __syncthreads();
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    const uint8_t* bufA = smem + cur * 2 * TILE_BYTES;
+    const uint8_t* bufW = bufA + TILE_BYTES;
+    const bool more = kt + 1 < KT;
+    if (more) stage_load<SPLIT>(g, m0, n0, kt + 1, KT1, tid, st);
+
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int kc = 4 * s + q;
+      bf16x8_t af[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wm * 64 + i * 16 + r;
+        af[i] = *reinterpret_cast<const bf16x8_t*>(bufA + row * 128 + ((kc ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wn * 64 + j * 16 + r;
+        wf[j] = *reinterpret_cast<const bf16x8_t*>(bufW + row * 128 + ((kc ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+    }
+
+    if (more) {
+      uint8_t* nA = smem + (cur ^ 1) * 2 * TILE_BYTES;
+      stage_write(nA, nA + TILE_BYTES, tid, st);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds D[n = 4q + e][m = r] of each 16x16 tile (e = 0..3)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + wm * 64 + i * 16 + r;
+    if (m >= g.M) continue;
+    int64_t orow = m;
+    const float* addrow = nullptr;
+    if (EPI == EPI_PATCH_F32) {
+      const int64_t b = m / g.rows_per_group;
+      const int p = (int)(m - b * g.rows_per_group);
+      orow = b * (g.rows_per_group + 1) + 1 + p;
+      addrow = g.add_table + (int64_t)(1 + p) * g.N;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + 4 * q;
+      f32x4_t v = acc[j][i];
+      if (EPI != EPI_PATCH_F32 && g.bias != nullptr) {
+        const float4 bv = *reinterpret_cast<const float4*>(g.bias + n);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+      }
+      if (EPI == EPI_PATCH_F32) {
+        const float4 pv = *reinterpret_cast<const float4*>(addrow + n);
+        v[0] += pv.x; v[1] += pv.y; v[2] += pv.z; v[3] += pv.w;
+      }
+      if (EPI == EPI_BIAS_GELU_BF16) {
+        if (g.act == 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_quick(v[e]);
+        }
+      }
+      if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16) {
+        bf16_t h[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (SPLIT) split_bf(v[e], h[e], l[e]);
+          else h[e] = f2bf(v[e]);
+        }
+        uint2 ph;
+        ph.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+        ph.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+        *reinterpret_cast<uint2*>(g.out_hi + orow * g.ldo + n) = ph;
+        if (SPLIT) {
+          uint2 pl;
+          pl.x = (uint32_t)l[0] | ((uint32_t)l[1] << 16);
+          pl.y = (uint32_t)l[2] | ((uint32_t)l[3] << 16);
+          *reinterpret_cast<uint2*>(g.out_lo + orow * g.ldo + n) = pl;
+        }
+      } else {
+        float4* dst = reinterpret_cast<float4*>(g.out_f32 + orow * g.ldo + n);
+        if (EPI == EPI_BIAS_RESID_F32) {
+          const float4 rv = *dst;
+          v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+        }
+        *dst = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+template <int EPI, bool SPLIT>
+hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  const int smem_bytes = 4 * TILE_BYTES;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<EPI, SPLIT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int64_t tiles_m = (a.M + BM - 1) / BM;
+  const int64_t nwg = tiles_m * (a.N / BN);
+  hipLaunchKernelGGL((gemm_kernel<EPI, SPLIT>), dim3((unsigned)nwg), dim3(256), smem_bytes, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_gemm(const GemmArgs& a, int epilogue, bool split, hipStream_t s) {
+  if (a.M <= 0 || a.N % BN != 0 || a.K % BK != 0 || a.K <= 0) return hipErrorInvalidValue;
+  if ((a.lda % 8) != 0 || (a.ldo % 4) != 0) return hipErrorInvalidValue;
+#define TAPCLIP_GEMM_CASE(E)                                      \
+  case E:                                                         \
+    return split ? launch_t<E, true>(a, s) : launch_t<E, false>(a, s);
+  switch (epilogue) {
+    TAPCLIP_GEMM_CASE(EPI_BIAS_BF16)
+    TAPCLIP_GEMM_CASE(EPI_BIAS_GELU_BF16)
+    TAPCLIP_GEMM_CASE(EPI_BIAS_RESID_F32)
+    TAPCLIP_GEMM_CASE(EPI_PATCH_F32)
+    TAPCLIP_GEMM_CASE(EPI_BIAS_F32)
+    default:
+      return hipErrorInvalidValue;
+  }
+#undef TAPCLIP_GEMM_CASE
+}
+
+}  // namespace tapclip

@@ -1,0 +1,84 @@
+// Host-callable launchers of the gfx950 kernels (internal; the public surface is include/tapclip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tapclip {
+
+typedef uint16_t bf16_t;
+
+enum Epilogue {
+  EPI_BIAS_BF16 = 0,       // out_hi(/lo)[m,n] = bf16(acc + bias[n])                      (QKV, K3)
+  EPI_BIAS_GELU_BF16 = 1,  // out_hi(/lo)[m,n] = bf16(act(acc + bias[n]))                 (c_fc, K6)
+  EPI_BIAS_RESID_F32 = 2,  // out_f32[m,n] += acc + bias[n]   (in-place residual add)     (out_proj K5, c_proj K7)
+  EPI_PATCH_F32 = 3,       // out_f32[b*(G2+1)+1+p, n] = acc + add_table[(1+p), n]        (patch embed, K1)
+  EPI_BIAS_F32 = 4,        // out_f32[m,n] = acc + bias[n]   (unit API / literal hook attn_out)
+};
+
+struct GemmArgs {
+  const bf16_t* A_hi;  // [M, K] activations, row stride lda
+  const bf16_t* A_lo;  // bf16x3 only
+  int64_t lda;
+  const bf16_t* W_hi;  // [N, K] weights (nn.Linear layout), row stride K
+  const bf16_t* W_lo;
+  const float* bias;   // [N] or nullptr
+  int64_t M;
+  int32_t N, K;
+  bf16_t* out_hi;
+  bf16_t* out_lo;
+  float* out_f32;
+  int64_t ldo;
+  const float* add_table;  // EPI_PATCH_F32: positional embedding [(G2+1), N]
+  int32_t rows_per_group;  // EPI_PATCH_F32: G2 patches per image
+  int32_t act;             // TAPCLIP_ACT_*
+};
+
+hipError_t launch_gemm(const GemmArgs& a, int epilogue, bool split, hipStream_t s);
+
+// LayerNorm over rows; one wave per row.  out_hi/out_lo (bf16) or out_f32; x may alias out_f32.
+hipError_t launch_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta,
+                            int64_t rows, int32_t d, bf16_t* out_hi, bf16_t* out_lo, float* out_f32,
+                            hipStream_t s);
+
+struct AttnArgs {
+  const bf16_t* qkv_hi;  // [n*T, 3D]: q | k | v, head h at columns h*64 .. h*64+63 of each third
+  const bf16_t* qkv_lo;
+  bf16_t* out_hi;        // [n*T, D]
+  bf16_t* out_lo;
+  float* probs;          // nullable [n, H, T, T] fp32 softmax probabilities
+  int32_t n_seq, T, H, D;
+  int32_t causal;
+};
+hipError_t launch_attention(const AttnArgs& a, bool split, hipStream_t s);
+
+// probs [n,H,T,T] -> mean over H -> [n,T,T]
+hipError_t launch_head_mean(const float* probs, int32_t n, int32_t H, int32_t T, float* out, hipStream_t s);
+
+// images [B,3,S,S] fp32 -> patches [B*G*G, Kp] bf16 (Kp = 3*p*p rounded up to 64, zero padded)
+hipError_t launch_im2col(const float* img, int32_t B, int32_t S, int32_t p, int32_t Kp, bf16_t* hi,
+                         bf16_t* lo, hipStream_t s);
+// x[b, 0, :] = class_embedding + pos[0]  (row stride: tokens*D)
+hipError_t launch_class_token(const float* cls, const float* pos, int32_t B, int32_t tokens, int32_t D,
+                              float* x, hipStream_t s);
+
+// fp32 -> bf16 hi (+lo); the first scale_rows rows (of row length cols) are multiplied by scale first.
+// src row stride = src_ld, dst row stride = dst_ld (>= cols, padding zero-filled).
+hipError_t launch_pack(const float* src, int64_t rows, int32_t cols, int64_t src_ld, int32_t dst_ld,
+                       int64_t scale_rows, float scale, bf16_t* hi, bf16_t* lo, hipStream_t s);
+hipError_t launch_scale_copy(const float* src, int64_t n, int64_t scale_n, float scale, float* dst, hipStream_t s);
+
+// out[i,:] = normalize?( LN?(src[i, idx_i, :]) @ proj[K, E] )
+hipError_t launch_pool_project(const float* src, int64_t n, int32_t tokens, int32_t K, const int64_t* index,
+                               int32_t fixed_token, const float* ln_g, const float* ln_b, const float* proj,
+                               int32_t E, int32_t normalize, float* out, hipStream_t s);
+
+hipError_t launch_embed_tokens(const float* table, int32_t vocab, const float* pos, const int64_t* tokens,
+                               int32_t n, int32_t L, int32_t D, int32_t add_pos, float* out, hipStream_t s);
+hipError_t launch_attribution(const float* amap, int32_t n, int32_t T, int32_t T2, int32_t P, int32_t normalize,
+                              float* out, hipStream_t s);
+hipError_t launch_build_prompts(const float* ctx, const float* tok, const float* attr, int32_t attr_cols,
+                                int32_t n, int32_t P, int32_t L, int32_t D, float* out, hipStream_t s);
+hipError_t launch_logits(const float* img, const float* txt, float scale, int32_t B, int32_t C, int32_t E,
+                         float* out, hipStream_t s);
+
+}  // namespace tapclip

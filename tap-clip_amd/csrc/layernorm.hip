@@ -1,0 +1,129 @@
+// LayerNorm (eps 1e-5, affine) as a wavefront reduction: one 64-lane wave per row, fp32 statistics.
+// Replaces the ln_pre / ln_1 / ln_2 / ln_post nn.LayerNorm calls inside open_clip's blocks
+// (SURVEY.md section 2.1 K2).  HBM-bound: reads the fp32 residual row once, writes the bf16 GEMM
+// operand (hi, and lo for bf16x3) or fp32 (ln_pre in place, unit API).
+#include "common.h"
+#include "kernels.h"
+
+namespace tapclip {
+namespace {
+
+// MODE 0: bf16 hi   1: bf16 hi + lo   2: fp32
+template <int MODE, int NV>  // NV float4 per lane: d = 256 * NV
+__global__ __launch_bounds__(256) void ln_vec_kernel(const float* __restrict__ x, int64_t ldx,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, int64_t rows, int d,
+                                                     bf16_t* out_hi, bf16_t* out_lo, float* out_f32) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * ldx;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    v[j] = *reinterpret_cast<const float4*>(xr + 4 * lane + 256 * j);
+    s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
+    ss += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)d + 1e-5f);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = 4 * lane + 256 * j;
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 bt = *reinterpret_cast<const float4*>(beta + c);
+    float y[4] = {v[j].x * rstd * gm.x + bt.x, v[j].y * rstd * gm.y + bt.y, v[j].z * rstd * gm.z + bt.z,
+                  v[j].w * rstd * gm.w + bt.w};
+    if (MODE == 2) {
+      *reinterpret_cast<float4*>(out_f32 + row * d + c) = make_float4(y[0], y[1], y[2], y[3]);
+    } else {
+      bf16_t h[4], l[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (MODE == 1) split_bf(y[e], h[e], l[e]);
+        else h[e] = f2bf(y[e]);
+      }
+      uint2 ph;
+      ph.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+      ph.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+      *reinterpret_cast<uint2*>(out_hi + row * d + c) = ph;
+      if (MODE == 1) {
+        uint2 pl;
+        pl.x = (uint32_t)l[0] | ((uint32_t)l[1] << 16);
+        pl.y = (uint32_t)l[2] | ((uint32_t)l[3] << 16);
+        *reinterpret_cast<uint2*>(out_lo + row * d + c) = pl;
+      }
+    }
+  }
+}
+
+// generic widths (d % 64 == 0, small test models): scalar, two passes over an L1-resident row
+template <int MODE>
+__global__ __launch_bounds__(256) void ln_generic_kernel(const float* __restrict__ x, int64_t ldx,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int64_t rows, int d,
+                                                         bf16_t* out_hi, bf16_t* out_lo, float* out_f32) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * ldx;
+  float s = 0.f;
+  for (int c = lane; c < d; c += 64) s += xr[c];
+  const float mean = wave_sum(s) / (float)d;
+  float ss = 0.f;
+  for (int c = lane; c < d; c += 64) {
+    const float t = xr[c] - mean;
+    ss += t * t;
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)d + 1e-5f);
+  // every lane has finished READING the row (the reductions above are wave-wide) before any write,
+  // so out_f32 may alias x
+  for (int c = lane; c < d; c += 64) {
+    const float y = (xr[c] - mean) * rstd * gamma[c] + beta[c];
+    if (MODE == 2) {
+      out_f32[row * d + c] = y;
+    } else if (MODE == 1) {
+      bf16_t h, l;
+      split_bf(y, h, l);
+      out_hi[row * d + c] = h;
+      out_lo[row * d + c] = l;
+    } else {
+      out_hi[row * d + c] = f2bf(y);
+    }
+  }
+}
+
+template <int MODE>
+hipError_t launch_mode(const float* x, int64_t ldx, const float* gamma, const float* beta, int64_t rows,
+                       int32_t d, bf16_t* hi, bf16_t* lo, float* f32, hipStream_t s) {
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (d % 256 == 0 && d / 256 <= 4 && ldx % 4 == 0) {
+    switch (d / 256) {
+      case 1: hipLaunchKernelGGL((ln_vec_kernel<MODE, 1>), grid, block, 0, s, x, ldx, gamma, beta, rows, d, hi, lo, f32); break;
+      case 2: hipLaunchKernelGGL((ln_vec_kernel<MODE, 2>), grid, block, 0, s, x, ldx, gamma, beta, rows, d, hi, lo, f32); break;
+      case 3: hipLaunchKernelGGL((ln_vec_kernel<MODE, 3>), grid, block, 0, s, x, ldx, gamma, beta, rows, d, hi, lo, f32); break;
+      default: hipLaunchKernelGGL((ln_vec_kernel<MODE, 4>), grid, block, 0, s, x, ldx, gamma, beta, rows, d, hi, lo, f32); break;
+    }
+  } else {
+    hipLaunchKernelGGL((ln_generic_kernel<MODE>), grid, block, 0, s, x, ldx, gamma, beta, rows, d, hi, lo, f32);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, int64_t rows,
+                            int32_t d, bf16_t* out_hi, bf16_t* out_lo, float* out_f32, hipStream_t s) {
+  if (rows <= 0 || d <= 0 || d % 64 != 0) return hipErrorInvalidValue;
+  if (out_f32 != nullptr) return launch_mode<2>(x, ldx, gamma, beta, rows, d, nullptr, nullptr, out_f32, s);
+  if (out_lo != nullptr) return launch_mode<1>(x, ldx, gamma, beta, rows, d, out_hi, out_lo, nullptr, s);
+  return launch_mode<0>(x, ldx, gamma, beta, rows, d, out_hi, nullptr, nullptr, s);
+}
+
+}  // namespace tapclip

@@ -1,0 +1,594 @@
+// Host side of the C ABI (include/tapclip.h): tower handles, weight packing, the per-layer launch
+// sequence of the vision and text towers, and the small standalone ops.  Kernels: gemm.hip,
+// layernorm.hip, attention.hip, elementwise.hip.
+//
+// Launch sequence of one pre-LN residual block (open_clip ResidualAttentionBlock, reached through
+// reference models/clip_wrapper.py:47 and models/model_wrapper.py:58,72):
+//   LN1 (fp32 x -> bf16)            layernorm.hip
+//   QKV GEMM + bias -> bf16 q|k|v   gemm.hip  EPI_BIAS_BF16      (1/sqrt(hd) folded into Wq, bq)
+//   attention core (+ probs)        attention.hip
+//   out_proj GEMM + bias + residual gemm.hip  EPI_BIAS_RESID_F32 (x updated in place, fp32)
+//   LN2                              layernorm.hip
+//   c_fc GEMM + bias + GELU -> bf16 gemm.hip  EPI_BIAS_GELU_BF16
+//   c_proj GEMM + bias + residual   gemm.hip  EPI_BIAS_RESID_F32
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/tapclip.h"
+#include "kernels.h"
+
+using namespace tapclip;
+
+namespace {
+
+thread_local char g_err[1024] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess)                                                                   \
+      return fail(TAPCLIP_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+struct Packed {  // a [rows, ld] bf16 matrix (hi, and lo for bf16x3)
+  bf16_t* hi = nullptr;
+  bf16_t* lo = nullptr;
+};
+
+struct LayerW {
+  float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
+  Packed wqkv, wo, wfc, wpr;
+  float *bqkv = nullptr, *bo = nullptr, *bfc = nullptr, *bpr = nullptr;
+};
+
+struct ProfRec {
+  int slot;
+  hipEvent_t start, stop;
+};
+
+size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct tapclip_tower {
+  tapclip_tower_cfg cfg;
+  bool split = false;
+  int tokens_vision = 0;  // G*G + 1
+  int Kp = 0;             // padded 3*p*p
+  std::vector<LayerW> layers;
+  std::vector<void*> allocs;
+  std::set<std::string> required, loaded;
+  // vision
+  Packed conv;
+  float *cls = nullptr, *pos = nullptr, *lnpre_g = nullptr, *lnpre_b = nullptr, *lnpost_g = nullptr,
+        *lnpost_b = nullptr, *proj = nullptr;
+  // text
+  float *tok_emb = nullptr, *lnfin_g = nullptr, *lnfin_b = nullptr, *text_proj = nullptr;
+  // profiling
+  bool prof_on = false;
+  std::vector<ProfRec> prof;
+  size_t prof_used = 0;
+  double prof_ms[TAPCLIP_PROFILE_SLOTS] = {0};
+  int64_t prof_n[TAPCLIP_PROFILE_SLOTS] = {0};
+};
+
+namespace {
+
+struct Workspace {
+  float* x = nullptr;
+  bf16_t *xn_hi = nullptr, *xn_lo = nullptr;
+  bf16_t *qkv_hi = nullptr, *qkv_lo = nullptr;
+  bf16_t *ao_hi = nullptr, *ao_lo = nullptr;
+  bf16_t *h_hi = nullptr, *h_lo = nullptr;
+  float* probs = nullptr;
+  size_t bytes = 0;
+};
+
+Workspace carve(const tapclip_tower* t, int64_t n_seq, int tokens, void* base) {
+  Workspace w;
+  const int64_t M = n_seq * tokens;
+  const int64_t D = t->cfg.width, F = t->cfg.mlp_dim;
+  // the im2col patch matrix aliases the MLP hidden buffer (never live together)
+  int64_t hid_elems = M * F;
+  if (t->cfg.kind == TAPCLIP_TOWER_VISION) {
+    const int64_t pe = n_seq * (tokens - 1) * (int64_t)t->Kp;
+    if (pe > hid_elems) hid_elems = pe;
+  }
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    void* p = base ? static_cast<char*>(base) + off : nullptr;
+    off += align_up(bytes);
+    return p;
+  };
+  w.x = static_cast<float*>(take(M * D * 4));
+  w.xn_hi = static_cast<bf16_t*>(take(M * D * 2));
+  w.qkv_hi = static_cast<bf16_t*>(take(M * 3 * D * 2));
+  w.ao_hi = static_cast<bf16_t*>(take(M * D * 2));
+  w.h_hi = static_cast<bf16_t*>(take(hid_elems * 2));
+  if (t->split) {
+    w.xn_lo = static_cast<bf16_t*>(take(M * D * 2));
+    w.qkv_lo = static_cast<bf16_t*>(take(M * 3 * D * 2));
+    w.ao_lo = static_cast<bf16_t*>(take(M * D * 2));
+    w.h_lo = static_cast<bf16_t*>(take(hid_elems * 2));
+  }
+  if (t->cfg.kind == TAPCLIP_TOWER_TEXT)
+    w.probs = static_cast<float*>(take((size_t)n_seq * t->cfg.heads * tokens * tokens * 4));
+  w.bytes = off;
+  return w;
+}
+
+struct ProfScope {
+  tapclip_tower* t;
+  hipStream_t s;
+  ProfRec* rec = nullptr;
+  ProfScope(tapclip_tower* tw, int slot, hipStream_t st) : t(tw), s(st) {
+    if (!t->prof_on) return;
+    if (t->prof_used == t->prof.size()) {
+      ProfRec r;
+      r.slot = slot;
+      if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
+      t->prof.push_back(r);
+    }
+    rec = &t->prof[t->prof_used++];
+    rec->slot = slot;
+    (void)hipEventRecord(rec->start, s);
+  }
+  ~ProfScope() {
+    if (rec) (void)hipEventRecord(rec->stop, s);
+  }
+};
+
+int dev_alloc(tapclip_tower* t, size_t bytes, void** out) {
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) return fail(TAPCLIP_ENOMEM, "hipMalloc(%zu) failed", bytes);
+  t->allocs.push_back(p);
+  *out = p;
+  return TAPCLIP_OK;
+}
+
+// copy an fp32 tensor into tower-owned memory (optionally scaling the first scale_n elements)
+int own_f32(tapclip_tower* t, const float* src, int64_t n, int64_t scale_n, float scale, float** dst, hipStream_t s) {
+  void* p;
+  int rc = dev_alloc(t, n * 4, &p);
+  if (rc) return rc;
+  HIP_TRY(launch_scale_copy(src, n, scale_n, scale, static_cast<float*>(p), s));
+  *dst = static_cast<float*>(p);
+  return TAPCLIP_OK;
+}
+
+int own_packed(tapclip_tower* t, const float* src, int64_t rows, int cols, int dst_ld, int64_t scale_rows, float scale,
+               Packed* out, hipStream_t s) {
+  void *h, *l = nullptr;
+  int rc = dev_alloc(t, rows * dst_ld * 2, &h);
+  if (rc) return rc;
+  if (t->split) {
+    rc = dev_alloc(t, rows * dst_ld * 2, &l);
+    if (rc) return rc;
+  }
+  HIP_TRY(launch_pack(src, rows, cols, cols, dst_ld, scale_rows, scale, static_cast<bf16_t*>(h),
+                      static_cast<bf16_t*>(l), s));
+  out->hi = static_cast<bf16_t*>(h);
+  out->lo = static_cast<bf16_t*>(l);
+  return TAPCLIP_OK;
+}
+
+bool shape_is(const int64_t* shape, int ndim, std::initializer_list<int64_t> want) {
+  if (ndim != (int)want.size()) return false;
+  int i = 0;
+  for (int64_t w : want)
+    if (shape[i++] != w) return false;
+  return true;
+}
+
+std::string shape_str(const int64_t* shape, int ndim) {
+  std::string s = "[";
+  for (int i = 0; i < ndim; ++i) s += (i ? "," : "") + std::to_string(shape[i]);
+  return s + "]";
+}
+
+int gemm(tapclip_tower* t, int slot, int epi, const bf16_t* a_hi, const bf16_t* a_lo, int64_t lda, const Packed& w,
+         const float* bias, int64_t M, int N, int K, bf16_t* o_hi, bf16_t* o_lo, float* o_f32, int64_t ldo,
+         hipStream_t s, const float* add_table = nullptr, int rows_per_group = 0) {
+  GemmArgs g;
+  g.A_hi = a_hi; g.A_lo = a_lo; g.lda = lda;
+  g.W_hi = w.hi; g.W_lo = w.lo;
+  g.bias = bias;
+  g.M = M; g.N = N; g.K = K;
+  g.out_hi = o_hi; g.out_lo = o_lo; g.out_f32 = o_f32; g.ldo = ldo;
+  g.add_table = add_table; g.rows_per_group = rows_per_group;
+  g.act = t->cfg.act;
+  ProfScope ps(t, slot, s);
+  HIP_TRY(launch_gemm(g, epi, t->split, s));
+  return TAPCLIP_OK;
+}
+
+// L residual blocks over x [n_seq*tokens, D] (fp32, updated in place)
+int run_blocks(tapclip_tower* t, float* x, int64_t n_seq, int tokens, int causal, const Workspace& w,
+               float* probs_last, float* attn_out_last, hipStream_t s) {
+  const int64_t M = n_seq * tokens;
+  const int D = t->cfg.width, F = t->cfg.mlp_dim, H = t->cfg.heads;
+  for (int li = 0; li < t->cfg.layers; ++li) {
+    const LayerW& L = t->layers[li];
+    const bool last = li == t->cfg.layers - 1;
+    {
+      ProfScope ps(t, 1, s);
+      HIP_TRY(launch_layernorm(x, D, L.ln1_g, L.ln1_b, M, D, w.xn_hi, w.xn_lo, nullptr, s));
+    }
+    int rc = gemm(t, 2, EPI_BIAS_BF16, w.xn_hi, w.xn_lo, D, L.wqkv, L.bqkv, M, 3 * D, D, w.qkv_hi, w.qkv_lo, nullptr,
+                  3 * D, s);
+    if (rc) return rc;
+    {
+      AttnArgs a;
+      a.qkv_hi = w.qkv_hi; a.qkv_lo = w.qkv_lo;
+      a.out_hi = w.ao_hi; a.out_lo = w.ao_lo;
+      a.probs = last ? probs_last : nullptr;
+      a.n_seq = (int)n_seq; a.T = tokens; a.H = H; a.D = D; a.causal = causal;
+      ProfScope ps(t, 3, s);
+      HIP_TRY(launch_attention(a, t->split, s));
+    }
+    if (last && attn_out_last != nullptr) {
+      // what the reference's hook literally captures: the attention module's output (pre residual)
+      rc = gemm(t, 4, EPI_BIAS_F32, w.ao_hi, w.ao_lo, D, L.wo, L.bo, M, D, D, nullptr, nullptr, attn_out_last, D, s);
+      if (rc) return rc;
+    }
+    rc = gemm(t, 4, EPI_BIAS_RESID_F32, w.ao_hi, w.ao_lo, D, L.wo, L.bo, M, D, D, nullptr, nullptr, x, D, s);
+    if (rc) return rc;
+    {
+      ProfScope ps(t, 1, s);
+      HIP_TRY(launch_layernorm(x, D, L.ln2_g, L.ln2_b, M, D, w.xn_hi, w.xn_lo, nullptr, s));
+    }
+    rc = gemm(t, 5, EPI_BIAS_GELU_BF16, w.xn_hi, w.xn_lo, D, L.wfc, L.bfc, M, F, D, w.h_hi, w.h_lo, nullptr, F, s);
+    if (rc) return rc;
+    rc = gemm(t, 6, EPI_BIAS_RESID_F32, w.h_hi, w.h_lo, F, L.wpr, L.bpr, M, D, F, nullptr, nullptr, x, D, s);
+    if (rc) return rc;
+  }
+  return TAPCLIP_OK;
+}
+
+int check_ready(const tapclip_tower* t) {
+  if (t->loaded.size() == t->required.size()) return TAPCLIP_OK;
+  std::string missing;
+  int n = 0;
+  for (const auto& k : t->required)
+    if (!t->loaded.count(k)) {
+      if (n++ < 6) missing += (missing.empty() ? "" : ", ") + k;
+    }
+  return fail(TAPCLIP_ESTATE, "tower is missing %d weight tensor(s): %s%s", n, missing.c_str(), n > 6 ? ", ..." : "");
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* tapclip_last_error(void) { return g_err; }
+int tapclip_abi_version(void) { return TAPCLIP_ABI_VERSION; }
+
+int tapclip_tower_create(const tapclip_tower_cfg* cfg, tapclip_tower_t** out) {
+  if (!cfg || !out) return fail(TAPCLIP_EINVAL, "null argument");
+  if (cfg->kind != TAPCLIP_TOWER_VISION && cfg->kind != TAPCLIP_TOWER_TEXT) return fail(TAPCLIP_EINVAL, "bad tower kind %d", cfg->kind);
+  if (cfg->width <= 0 || cfg->width % 128 != 0) return fail(TAPCLIP_EINVAL, "width %d must be a positive multiple of 128", cfg->width);
+  if (cfg->heads <= 0 || cfg->width != cfg->heads * 64) return fail(TAPCLIP_EINVAL, "head dim must be 64 (width %d, heads %d)", cfg->width, cfg->heads);
+  if (cfg->mlp_dim <= 0 || cfg->mlp_dim % 128 != 0) return fail(TAPCLIP_EINVAL, "mlp_dim %d must be a positive multiple of 128", cfg->mlp_dim);
+  if (cfg->layers <= 0 || cfg->embed_dim <= 0 || cfg->embed_dim > 1024) return fail(TAPCLIP_EINVAL, "bad layers/embed_dim");
+  if (cfg->precision != TAPCLIP_PREC_BF16 && cfg->precision != TAPCLIP_PREC_BF16X3) return fail(TAPCLIP_EINVAL, "bad precision %d", cfg->precision);
+  if (cfg->act != TAPCLIP_ACT_GELU_ERF && cfg->act != TAPCLIP_ACT_QUICK_GELU) return fail(TAPCLIP_EINVAL, "bad activation %d", cfg->act);
+  tapclip_tower* t = new tapclip_tower();
+  t->cfg = *cfg;
+  t->split = cfg->precision == TAPCLIP_PREC_BF16X3;
+  t->layers.resize(cfg->layers);
+  if (cfg->kind == TAPCLIP_TOWER_VISION) {
+    if (cfg->patch <= 0 || cfg->image_size <= 0 || cfg->image_size % cfg->patch != 0) {
+      delete t;
+      return fail(TAPCLIP_EINVAL, "image_size %d must be a positive multiple of patch %d", cfg->image_size, cfg->patch);
+    }
+    const int G = cfg->image_size / cfg->patch;
+    t->tokens_vision = G * G + 1;
+    if (t->tokens_vision > 256) {
+      delete t;
+      return fail(TAPCLIP_EINVAL, "%d tokens per image: the attention kernel holds at most 256 keys", t->tokens_vision);
+    }
+    t->Kp = (3 * cfg->patch * cfg->patch + 63) / 64 * 64;
+    for (const char* k : {"conv1.weight", "class_embedding", "positional_embedding", "ln_pre.weight", "ln_pre.bias",
+                          "ln_post.weight", "ln_post.bias", "proj"})
+      t->required.insert(k);
+  } else {
+    if (cfg->ctx_len <= 0 || cfg->vocab <= 0) {
+      delete t;
+      return fail(TAPCLIP_EINVAL, "text tower needs ctx_len and vocab");
+    }
+    for (const char* k : {"token_embedding.weight", "positional_embedding", "ln_final.weight", "ln_final.bias", "text_projection"})
+      t->required.insert(k);
+  }
+  for (int i = 0; i < cfg->layers; ++i)
+    for (const char* k : {"ln_1.weight", "ln_1.bias", "attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight",
+                          "attn.out_proj.bias", "ln_2.weight", "ln_2.bias", "mlp.c_fc.weight", "mlp.c_fc.bias",
+                          "mlp.c_proj.weight", "mlp.c_proj.bias"})
+      t->required.insert("transformer.resblocks." + std::to_string(i) + "." + k);
+  *out = t;
+  return TAPCLIP_OK;
+}
+
+void tapclip_tower_destroy(tapclip_tower_t* t) {
+  if (!t) return;
+  for (void* p : t->allocs) (void)hipFree(p);
+  for (auto& r : t->prof) {
+    (void)hipEventDestroy(r.start);
+    (void)hipEventDestroy(r.stop);
+  }
+  delete t;
+}
+
+int tapclip_tower_load_weight(tapclip_tower_t* t, const char* key_c, const float* src, const int64_t* shape, int32_t ndim,
+                              tapclip_stream_t stream) {
+  if (!t || !key_c || !src || !shape) return fail(TAPCLIP_EINVAL, "null argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const std::string key(key_c);
+  if (!t->required.count(key)) return fail(TAPCLIP_EINVAL, "unexpected key '%s' for this tower", key_c);
+  if (t->loaded.count(key)) return fail(TAPCLIP_ESTATE, "key '%s' loaded twice", key_c);
+  const int64_t D = t->cfg.width, F = t->cfg.mlp_dim, E = t->cfg.embed_dim;
+  auto bad = [&](const char* want) {
+    return fail(TAPCLIP_EINVAL, "size mismatch for %s: got %s, expected %s", key_c, shape_str(shape, ndim).c_str(), want);
+  };
+  int rc = TAPCLIP_OK;
+  const std::string pre = "transformer.resblocks.";
+  if (key.compare(0, pre.size(), pre) == 0) {
+    const size_t dot = key.find('.', pre.size());
+    const int li = atoi(key.substr(pre.size(), dot - pre.size()).c_str());
+    const std::string sub = key.substr(dot + 1);
+    LayerW& L = t->layers[li];
+    auto vec = [&](int64_t n, float** dst, int64_t scale_n = 0, float scale = 1.f) {
+      if (!shape_is(shape, ndim, {n})) return bad(("[" + std::to_string(n) + "]").c_str());
+      return own_f32(t, src, n, scale_n, scale, dst, s);
+    };
+    auto mat = [&](int64_t rows, int64_t cols, Packed* dst, int64_t scale_rows = 0, float scale = 1.f) {
+      if (!shape_is(shape, ndim, {rows, cols})) return bad(("[" + std::to_string(rows) + "," + std::to_string(cols) + "]").c_str());
+      return own_packed(t, src, rows, (int)cols, (int)cols, scale_rows, scale, dst, s);
+    };
+    const float qscale = 1.0f / sqrtf(64.0f);  // folded softmax scale; exact in bf16
+    if (sub == "ln_1.weight") rc = vec(D, &L.ln1_g);
+    else if (sub == "ln_1.bias") rc = vec(D, &L.ln1_b);
+    else if (sub == "ln_2.weight") rc = vec(D, &L.ln2_g);
+    else if (sub == "ln_2.bias") rc = vec(D, &L.ln2_b);
+    else if (sub == "attn.in_proj_weight") rc = mat(3 * D, D, &L.wqkv, D, qscale);
+    else if (sub == "attn.in_proj_bias") rc = vec(3 * D, &L.bqkv, D, qscale);
+    else if (sub == "attn.out_proj.weight") rc = mat(D, D, &L.wo);
+    else if (sub == "attn.out_proj.bias") rc = vec(D, &L.bo);
+    else if (sub == "mlp.c_fc.weight") rc = mat(F, D, &L.wfc);
+    else if (sub == "mlp.c_fc.bias") rc = vec(F, &L.bfc);
+    else if (sub == "mlp.c_proj.weight") rc = mat(D, F, &L.wpr);
+    else if (sub == "mlp.c_proj.bias") rc = vec(D, &L.bpr);
+    else return fail(TAPCLIP_EINVAL, "unexpected key '%s'", key_c);
+  } else if (t->cfg.kind == TAPCLIP_TOWER_VISION) {
+    const int64_t p = t->cfg.patch, N = t->tokens_vision;
+    if (key == "conv1.weight") {
+      if (!shape_is(shape, ndim, {D, 3, p, p})) return bad("[width,3,patch,patch]");
+      rc = own_packed(t, src, D, (int)(3 * p * p), t->Kp, 0, 1.f, &t->conv, s);
+    } else if (key == "class_embedding") {
+      if (!shape_is(shape, ndim, {D})) return bad("[width]");
+      rc = own_f32(t, src, D, 0, 1.f, &t->cls, s);
+    } else if (key == "positional_embedding") {
+      if (!shape_is(shape, ndim, {N, D})) return bad("[tokens,width]");
+      rc = own_f32(t, src, N * D, 0, 1.f, &t->pos, s);
+    } else if (key == "proj") {
+      if (!shape_is(shape, ndim, {D, E})) return bad("[width,embed_dim]");
+      rc = own_f32(t, src, D * E, 0, 1.f, &t->proj, s);
+    } else {
+      if (!shape_is(shape, ndim, {D})) return bad("[width]");
+      float** dst = key == "ln_pre.weight" ? &t->lnpre_g : key == "ln_pre.bias" ? &t->lnpre_b : key == "ln_post.weight" ? &t->lnpost_g : &t->lnpost_b;
+      rc = own_f32(t, src, D, 0, 1.f, dst, s);
+    }
+  } else {
+    if (key == "token_embedding.weight") {
+      if (!shape_is(shape, ndim, {(int64_t)t->cfg.vocab, D})) return bad("[vocab,width]");
+      rc = own_f32(t, src, (int64_t)t->cfg.vocab * D, 0, 1.f, &t->tok_emb, s);
+    } else if (key == "positional_embedding") {
+      if (!shape_is(shape, ndim, {(int64_t)t->cfg.ctx_len, D})) return bad("[ctx_len,width]");
+      rc = own_f32(t, src, (int64_t)t->cfg.ctx_len * D, 0, 1.f, &t->pos, s);
+    } else if (key == "text_projection") {
+      if (!shape_is(shape, ndim, {D, E})) return bad("[width,embed_dim]");
+      rc = own_f32(t, src, D * E, 0, 1.f, &t->text_proj, s);
+    } else {
+      if (!shape_is(shape, ndim, {D})) return bad("[width]");
+      rc = own_f32(t, src, D, 0, 1.f, key == "ln_final.weight" ? &t->lnfin_g : &t->lnfin_b, s);
+    }
+  }
+  if (rc) return rc;
+  t->loaded.insert(key);
+  return TAPCLIP_OK;
+}
+
+int tapclip_tower_ready(const tapclip_tower_t* t) {
+  if (!t) return fail(TAPCLIP_EINVAL, "null tower");
+  return check_ready(t);
+}
+
+size_t tapclip_tower_workspace_bytes(const tapclip_tower_t* t, int64_t n_seq, int32_t tokens) {
+  if (!t || n_seq <= 0 || tokens <= 0) return 0;
+  return carve(t, n_seq, tokens, nullptr).bytes;
+}
+
+int tapclip_encode_image(tapclip_tower_t* t, const float* images, int32_t B, float* out, int32_t normalize,
+                         void* workspace, size_t workspace_bytes, tapclip_stream_t stream) {
+  if (!t || !images || !out || !workspace) return fail(TAPCLIP_EINVAL, "null argument");
+  if (t->cfg.kind != TAPCLIP_TOWER_VISION) return fail(TAPCLIP_EINVAL, "encode_image needs a vision tower");
+  if (B <= 0) return fail(TAPCLIP_EINVAL, "batch must be positive");
+  int rc = check_ready(t);
+  if (rc) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int N = t->tokens_vision, D = t->cfg.width, G2 = N - 1;
+  const Workspace w = carve(t, B, N, workspace);
+  if (w.bytes > workspace_bytes) return fail(TAPCLIP_EWORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, w.bytes);
+  {
+    ProfScope ps(t, 0, s);
+    // patch gather into the (not yet live) MLP-hidden buffer, then conv1-as-GEMM with the
+    // positional-embedding add and the [b, 1+p] row placement fused into the epilogue
+    HIP_TRY(launch_im2col(images, B, t->cfg.image_size, t->cfg.patch, t->Kp, w.h_hi, w.h_lo, s));
+    GemmArgs g;
+    g.A_hi = w.h_hi; g.A_lo = w.h_lo; g.lda = t->Kp;
+    g.W_hi = t->conv.hi; g.W_lo = t->conv.lo;
+    g.bias = nullptr;
+    g.M = (int64_t)B * G2; g.N = D; g.K = t->Kp;
+    g.out_hi = nullptr; g.out_lo = nullptr; g.out_f32 = w.x; g.ldo = D;
+    g.add_table = t->pos; g.rows_per_group = G2; g.act = 0;
+    HIP_TRY(launch_gemm(g, EPI_PATCH_F32, t->split, s));
+    HIP_TRY(launch_class_token(t->cls, t->pos, B, N, D, w.x, s));
+  }
+  {
+    ProfScope ps(t, 1, s);
+    HIP_TRY(launch_layernorm(w.x, D, t->lnpre_g, t->lnpre_b, (int64_t)B * N, D, nullptr, nullptr, w.x, s));
+  }
+  rc = run_blocks(t, w.x, B, N, 0, w, nullptr, nullptr, s);
+  if (rc) return rc;
+  {
+    ProfScope ps(t, 7, s);
+    HIP_TRY(launch_pool_project(w.x, B, N, D, nullptr, 0, t->lnpost_g, t->lnpost_b, t->proj, t->cfg.embed_dim, normalize, out, s));
+  }
+  return TAPCLIP_OK;
+}
+
+int tapclip_text_forward(tapclip_tower_t* t, const float* x_in, int32_t n_seq, int32_t tokens, int32_t causal,
+                         float* out_hidden, float* attn_heads, float* attn_mean, float* attn_out, void* workspace,
+                         size_t workspace_bytes, tapclip_stream_t stream) {
+  if (!t || !x_in || !workspace) return fail(TAPCLIP_EINVAL, "null argument");
+  if (t->cfg.kind != TAPCLIP_TOWER_TEXT) return fail(TAPCLIP_EINVAL, "text_forward needs a text tower");
+  if (n_seq <= 0 || tokens <= 0 || tokens > 256) return fail(TAPCLIP_EINVAL, "bad n_seq/tokens (%d, %d); tokens <= 256", n_seq, tokens);
+  int rc = check_ready(t);
+  if (rc) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int D = t->cfg.width;
+  const Workspace w = carve(t, n_seq, tokens, workspace);
+  if (w.bytes > workspace_bytes) return fail(TAPCLIP_EWORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, w.bytes);
+  float* x = out_hidden ? out_hidden : w.x;  // the residual stream lives in the caller's output
+  if (x != x_in) HIP_TRY(hipMemcpyAsync(x, x_in, (size_t)n_seq * tokens * D * 4, hipMemcpyDeviceToDevice, s));
+  float* probs = attn_heads ? attn_heads : (attn_mean ? w.probs : nullptr);
+  rc = run_blocks(t, x, n_seq, tokens, causal, w, probs, attn_out, s);
+  if (rc) return rc;
+  if (attn_mean) HIP_TRY(launch_head_mean(probs, n_seq, t->cfg.heads, tokens, attn_mean, s));
+  return TAPCLIP_OK;
+}
+
+int tapclip_text_pool_project(tapclip_tower_t* t, const float* hidden, int32_t n_seq, int32_t tokens, const int64_t* index,
+                              int32_t apply_ln_final, int32_t normalize, float* out, tapclip_stream_t stream) {
+  if (!t || !hidden || !out) return fail(TAPCLIP_EINVAL, "null argument");
+  if (t->cfg.kind != TAPCLIP_TOWER_TEXT) return fail(TAPCLIP_EINVAL, "needs a text tower");
+  int rc = check_ready(t);
+  if (rc) return rc;
+  HIP_TRY(launch_pool_project(hidden, n_seq, tokens, t->cfg.width, index, -1, apply_ln_final ? t->lnfin_g : nullptr,
+                              apply_ln_final ? t->lnfin_b : nullptr, t->text_proj, t->cfg.embed_dim, normalize, out,
+                              static_cast<hipStream_t>(stream)));
+  return TAPCLIP_OK;
+}
+
+int tapclip_embed_tokens(tapclip_tower_t* t, const int64_t* tokens, int32_t n_seq, int32_t len, int32_t add_pos, float* out,
+                         tapclip_stream_t stream) {
+  if (!t || !tokens || !out) return fail(TAPCLIP_EINVAL, "null argument");
+  if (t->cfg.kind != TAPCLIP_TOWER_TEXT) return fail(TAPCLIP_EINVAL, "needs a text tower");
+  if (!t->tok_emb || !t->pos) return fail(TAPCLIP_ESTATE, "token_embedding / positional_embedding not loaded");
+  if (add_pos && len > t->cfg.ctx_len) return fail(TAPCLIP_EINVAL, "len %d > ctx_len %d", len, t->cfg.ctx_len);
+  HIP_TRY(launch_embed_tokens(t->tok_emb, t->cfg.vocab, t->pos, tokens, n_seq, len, t->cfg.width, add_pos, out,
+                              static_cast<hipStream_t>(stream)));
+  return TAPCLIP_OK;
+}
+
+int tapclip_attribution(const float* attn_map, int32_t n, int32_t T, int32_t T2, int32_t P, int32_t normalize, float* out,
+                        tapclip_stream_t stream) {
+  if (!attn_map || !out || n <= 0 || T <= 0 || T2 < T || P <= 0) return fail(TAPCLIP_EINVAL, "bad attribution arguments");
+  HIP_TRY(launch_attribution(attn_map, n, T, T2, P, normalize, out, static_cast<hipStream_t>(stream)));
+  return TAPCLIP_OK;
+}
+
+int tapclip_build_prompts(const float* ctx, const float* tok, const float* attribution, int32_t attr_cols, int32_t n,
+                          int32_t P, int32_t L, int32_t D, float* out, tapclip_stream_t stream) {
+  if (!ctx || !tok || !out || n <= 0 || P <= 0 || L <= 0 || D <= 0) return fail(TAPCLIP_EINVAL, "bad build_prompts arguments");
+  if (attribution && attr_cols != P && attr_cols != 1) return fail(TAPCLIP_EINVAL, "attribution has %d columns, expected %d or 1", attr_cols, P);
+  HIP_TRY(launch_build_prompts(ctx, tok, attribution, attr_cols, n, P, L, D, out, static_cast<hipStream_t>(stream)));
+  return TAPCLIP_OK;
+}
+
+int tapclip_logits(const float* img, const float* txt, float scale, int32_t B, int32_t C, int32_t E, float* out,
+                   tapclip_stream_t stream) {
+  if (!img || !txt || !out || B <= 0 || C <= 0 || E <= 0) return fail(TAPCLIP_EINVAL, "bad logits arguments");
+  HIP_TRY(launch_logits(img, txt, scale, B, C, E, out, static_cast<hipStream_t>(stream)));
+  return TAPCLIP_OK;
+}
+
+int tapclip_layernorm_f32(const float* x, const float* gamma, const float* beta, int64_t rows, int32_t d, float* y,
+                          tapclip_stream_t stream) {
+  if (!x || !gamma || !beta || !y) return fail(TAPCLIP_EINVAL, "null argument");
+  if (rows <= 0 || d <= 0 || d % 64 != 0) return fail(TAPCLIP_EINVAL, "layernorm needs rows > 0 and d %% 64 == 0 (got %lld, %d)", (long long)rows, d);
+  HIP_TRY(launch_layernorm(x, d, gamma, beta, rows, d, nullptr, nullptr, y, static_cast<hipStream_t>(stream)));
+  return TAPCLIP_OK;
+}
+
+size_t tapclip_gemm_scratch_bytes(int64_t M, int32_t N, int32_t K) {
+  return 2 * (align_up((size_t)M * K * 2) + align_up((size_t)N * K * 2));
+}
+
+int tapclip_gemm_f32(const float* A, const float* W, const float* bias, int64_t M, int32_t N, int32_t K, int32_t precision,
+                     float* C, void* scratch, size_t scratch_bytes, tapclip_stream_t stream) {
+  if (!A || !W || !C || !scratch) return fail(TAPCLIP_EINVAL, "null argument");
+  if (M <= 0 || N <= 0 || N % 128 != 0 || K <= 0 || K % 64 != 0) return fail(TAPCLIP_EINVAL, "gemm needs N %% 128 == 0 and K %% 64 == 0 (M %lld N %d K %d)", (long long)M, N, K);
+  if (scratch_bytes < tapclip_gemm_scratch_bytes(M, N, K)) return fail(TAPCLIP_EWORKSPACE, "gemm scratch too small");
+  const bool split = precision == TAPCLIP_PREC_BF16X3;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  char* p = static_cast<char*>(scratch);
+  bf16_t* a_hi = reinterpret_cast<bf16_t*>(p); p += align_up((size_t)M * K * 2);
+  bf16_t* a_lo = reinterpret_cast<bf16_t*>(p); p += align_up((size_t)M * K * 2);
+  bf16_t* w_hi = reinterpret_cast<bf16_t*>(p); p += align_up((size_t)N * K * 2);
+  bf16_t* w_lo = reinterpret_cast<bf16_t*>(p);
+  HIP_TRY(launch_pack(A, M, K, K, K, 0, 1.f, a_hi, split ? a_lo : nullptr, s));
+  HIP_TRY(launch_pack(W, N, K, K, K, 0, 1.f, w_hi, split ? w_lo : nullptr, s));
+  GemmArgs g;
+  g.A_hi = a_hi; g.A_lo = a_lo; g.lda = K;
+  g.W_hi = w_hi; g.W_lo = w_lo;
+  g.bias = bias;
+  g.M = M; g.N = N; g.K = K;
+  g.out_hi = nullptr; g.out_lo = nullptr; g.out_f32 = C; g.ldo = N;
+  g.add_table = nullptr; g.rows_per_group = 0; g.act = 0;
+  HIP_TRY(launch_gemm(g, EPI_BIAS_F32, split, s));
+  return TAPCLIP_OK;
+}
+
+int tapclip_profile_enable(tapclip_tower_t* t, int32_t on) {
+  if (!t) return fail(TAPCLIP_EINVAL, "null tower");
+  t->prof_on = on != 0;
+  return TAPCLIP_OK;
+}
+
+int tapclip_profile_read(tapclip_tower_t* t, float* ms_out, int64_t* launches_out) {
+  if (!t || !ms_out || !launches_out) return fail(TAPCLIP_EINVAL, "null argument");
+  for (size_t i = 0; i < t->prof_used; ++i) {
+    ProfRec& r = t->prof[i];
+    HIP_TRY(hipEventSynchronize(r.stop));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, r.start, r.stop));
+    t->prof_ms[r.slot] += ms;
+    t->prof_n[r.slot] += 1;
+  }
+  t->prof_used = 0;
+  for (int i = 0; i < TAPCLIP_PROFILE_SLOTS; ++i) {
+    ms_out[i] = (float)t->prof_ms[i];
+    launches_out[i] = t->prof_n[i];
+    t->prof_ms[i] = 0;
+    t->prof_n[i] = 0;
+  }
+  return TAPCLIP_OK;
+}
+
+}  // extern "C"

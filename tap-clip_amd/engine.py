@@ -1,0 +1,246 @@
+"""Thin Python handles over the C-ABI towers (include/tapclip.h).  PyTorch only supplies device
+memory and the current HIP stream; all arithmetic happens in libtapclip.so.
+
+`VisionTower` / `TextTower` replace the open_clip model that reference
+models/clip_wrapper.py:13-16 builds and loads."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+from .configs import ClipDims, TowerDims
+
+
+def _stream_ptr(device: torch.device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _dev_f32(t: torch.Tensor, device: torch.device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class _Tower:
+    kind = -1
+    prefix = ""
+
+    def __init__(self, cfg: ClipDims, dims: TowerDims, state_dict: Dict[str, torch.Tensor], device, precision: str):
+        if precision not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {precision!r}")
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("tapclip towers run on an AMD GPU only (device must be 'cuda[:i]'); there is no CPU path")
+        self.cfg, self.dims, self.precision = cfg, dims, precision
+        c = _lib.TowerCfg(
+            kind=self.kind, width=dims.width, layers=dims.layers, heads=dims.heads, mlp_dim=dims.mlp,
+            embed_dim=cfg.embed_dim, image_size=cfg.image_size, patch=cfg.patch, ctx_len=cfg.ctx, vocab=cfg.vocab,
+            act=_lib.ACT_QUICK_GELU if cfg.quick_gelu else _lib.ACT_GELU_ERF, precision=_lib.PRECISIONS[precision],
+        )
+        h = C.c_void_p()
+        _lib.check(self.lib.tapclip_tower_create(C.byref(c), C.byref(h)))
+        self.handle = h
+        self._ws: Optional[torch.Tensor] = None
+        self._load(state_dict)
+
+    # -- weights -----------------------------------------------------------------------------
+    def _wanted(self, key: str) -> Optional[str]:
+        raise NotImplementedError
+
+    def _load(self, state_dict: Dict[str, torch.Tensor]) -> None:
+        with torch.cuda.device(self.device):
+            stream = _stream_ptr(self.device)
+            for key, t in state_dict.items():
+                name = self._wanted(key)
+                if name is None:
+                    continue
+                d = _dev_f32(t, self.device)
+                shape = (C.c_int64 * max(d.dim(), 1))(*d.shape)
+                _lib.check(self.lib.tapclip_tower_load_weight(self.handle, name.encode(), _ptr(d), shape, d.dim(), stream))
+            torch.cuda.current_stream(self.device).synchronize()  # staging tensors may now be freed
+        _lib.check(self.lib.tapclip_tower_ready(self.handle))  # strict=True semantics
+
+    # -- scratch -----------------------------------------------------------------------------
+    def workspace(self, n_seq: int, tokens: int) -> Tuple[torch.Tensor, int]:
+        need = int(self.lib.tapclip_tower_workspace_bytes(self.handle, n_seq, tokens))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws, self._ws.numel()
+
+    # -- per-stage HIP-event timing ------------------------------------------------------------
+    def profile(self, on: bool) -> None:
+        _lib.check(self.lib.tapclip_profile_enable(self.handle, int(on)))
+
+    def profile_read(self) -> Dict[str, Tuple[float, int]]:
+        ms = (C.c_float * len(_lib.PROFILE_SLOTS))()
+        n = (C.c_int64 * len(_lib.PROFILE_SLOTS))()
+        _lib.check(self.lib.tapclip_profile_read(self.handle, ms, n))
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(_lib.PROFILE_SLOTS)}
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.tapclip_tower_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class VisionTower(_Tower):
+    kind = _lib.TOWER_VISION
+
+    def __init__(self, cfg: ClipDims, state_dict, device="cuda", precision: str = "bf16"):
+        super().__init__(cfg, cfg.vision, state_dict, device, precision)
+
+    def _wanted(self, key):
+        return key[len("visual."):] if key.startswith("visual.") else None
+
+    def encode_image(self, images: torch.Tensor, normalize: bool = False) -> torch.Tensor:
+        """`CLIPWrapper.encode_image` (reference models/clip_wrapper.py:46-47): [B,3,S,S] -> [B,E]."""
+        s = self.cfg.image_size
+        if images.dim() != 4 or tuple(images.shape[1:]) != (3, s, s):
+            raise ValueError(f"expected images [B,3,{s},{s}], got {tuple(images.shape)}")
+        x = _dev_f32(images, self.device)
+        B = x.shape[0]
+        out = torch.empty(B, self.cfg.embed_dim, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            ws, nbytes = self.workspace(B, self.cfg.n_tokens)
+            _lib.check(self.lib.tapclip_encode_image(self.handle, _ptr(x), B, _ptr(out), int(normalize), _ptr(ws),
+                                                     nbytes, _stream_ptr(self.device)))
+        return out
+
+
+class TextTower(_Tower):
+    kind = _lib.TOWER_TEXT
+    _TOP = ("token_embedding.weight", "positional_embedding", "ln_final.weight", "ln_final.bias", "text_projection")
+
+    def __init__(self, cfg: ClipDims, state_dict, device="cuda", precision: str = "bf16"):
+        super().__init__(cfg, cfg.text, state_dict, device, precision)
+
+    def _wanted(self, key):
+        if key.startswith("transformer.resblocks.") or key in self._TOP:
+            return key
+        return None
+
+    def forward(self, x: torch.Tensor, causal: bool = False, want_hidden: bool = True, want_heads: bool = False,
+                want_mean: bool = False, want_attn_out: bool = False):
+        """`clip.model.transformer(x)` (reference models/model_wrapper.py:58,72) on [n,T,D].
+        Returns dict with any of hidden [n,T,D], attn_heads [n,H,T,T], attn_mean [n,T,T], attn_out [n,T,D]."""
+        D = self.dims.width
+        if x.dim() != 3 or x.shape[-1] != D:
+            raise ValueError(f"expected x [n,T,{D}], got {tuple(x.shape)}")
+        xin = _dev_f32(x, self.device)
+        n, T, _ = xin.shape
+        mk = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=self.device)
+        hidden = mk(n, T, D) if want_hidden else None
+        heads = mk(n, self.dims.heads, T, T) if want_heads else None
+        mean = mk(n, T, T) if want_mean else None
+        aout = mk(n, T, D) if want_attn_out else None
+        with torch.cuda.device(self.device):
+            ws, nbytes = self.workspace(n, T)
+            _lib.check(self.lib.tapclip_text_forward(self.handle, _ptr(xin), n, T, int(causal), _ptr(hidden), _ptr(heads),
+                                                     _ptr(mean), _ptr(aout), _ptr(ws), nbytes, _stream_ptr(self.device)))
+        return {"hidden": hidden, "attn_heads": heads, "attn_mean": mean, "attn_out": aout}
+
+    def pool_project(self, hidden: torch.Tensor, index: Optional[torch.Tensor] = None, ln_final: bool = False,
+                     normalize: bool = False) -> torch.Tensor:
+        """token pick (-1 or index) [-> ln_final] -> @ text_projection [-> L2 norm]
+        (reference models/model_wrapper.py:73-75; encode_text tail)."""
+        h = _dev_f32(hidden, self.device)
+        n, T, _ = h.shape
+        idx = None if index is None else index.to(device=self.device, dtype=torch.int64).contiguous()
+        out = torch.empty(n, self.cfg.embed_dim, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.tapclip_text_pool_project(self.handle, _ptr(h), n, T, _ptr(idx), int(ln_final),
+                                                          int(normalize), _ptr(out), _stream_ptr(self.device)))
+        return out
+
+    def embed_tokens(self, tokens: torch.Tensor, add_pos: bool) -> torch.Tensor:
+        t = tokens.to(device=self.device, dtype=torch.int64).contiguous()
+        if t.dim() != 2:
+            raise ValueError(f"expected tokens [n,L], got {tuple(t.shape)}")
+        n, L = t.shape
+        out = torch.empty(n, L, self.dims.width, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.tapclip_embed_tokens(self.handle, _ptr(t), n, L, int(add_pos), _ptr(out), _stream_ptr(self.device)))
+        return out
+
+
+# ---- standalone ops ------------------------------------------------------------------------------
+def attribution(attn_map: torch.Tensor, prompt_len: int, normalize: bool = True) -> torch.Tensor:
+    """`AttributionMonitor.forward` (reference models/attribution_monitor.py:17-36)."""
+    if attn_map.dim() != 3:
+        raise ValueError(f"expected attn_map [B,T,T], got {tuple(attn_map.shape)}")
+    a = attn_map.detach().to(torch.float32).contiguous()
+    n, T, T2 = a.shape
+    rows = min(prompt_len, T)
+    out = torch.empty(n, rows, dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().tapclip_attribution(_ptr(a), n, T, T2, prompt_len, int(normalize), _ptr(out), _stream_ptr(a.device)))
+    return out
+
+
+def build_prompts(ctx: torch.Tensor, tok: torch.Tensor, attr: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """cat([ctx * attr[..., None], tok], dim=1) (reference models/prompt_adjustor.py:35-36,
+    models/model_wrapper.py:51,68-69)."""
+    c = ctx.detach().to(torch.float32).contiguous()
+    t = tok.detach().to(device=c.device, dtype=torch.float32).contiguous()
+    n, P, D = c.shape
+    L = t.shape[1]
+    a = None if attr is None else attr.detach().to(device=c.device, dtype=torch.float32).contiguous()
+    out = torch.empty(n, P + L, D, dtype=torch.float32, device=c.device)
+    with torch.cuda.device(c.device):
+        _lib.check(_lib.load().tapclip_build_prompts(_ptr(c), _ptr(t), _ptr(a), 0 if a is None else a.shape[1], n, P, L, D,
+                                                     _ptr(out), _stream_ptr(c.device)))
+    return out
+
+
+def logits(img: torch.Tensor, txt: torch.Tensor, scale: float) -> torch.Tensor:
+    """scale * img @ txt.T (reference models/model_wrapper.py:79,83)."""
+    i = img.detach().to(torch.float32).contiguous()
+    t = txt.detach().to(device=i.device, dtype=torch.float32).contiguous()
+    B, E = i.shape
+    Cn = t.shape[0]
+    out = torch.empty(B, Cn, dtype=torch.float32, device=i.device)
+    with torch.cuda.device(i.device):
+        _lib.check(_lib.load().tapclip_logits(_ptr(i), _ptr(t), float(scale), B, Cn, E, _ptr(out), _stream_ptr(i.device)))
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
+    xx = x.detach().to(torch.float32).contiguous()
+    d = xx.shape[-1]
+    rows = xx.numel() // d
+    y = torch.empty_like(xx)
+    g = gamma.detach().to(device=xx.device, dtype=torch.float32).contiguous()
+    b = beta.detach().to(device=xx.device, dtype=torch.float32).contiguous()
+    with torch.cuda.device(xx.device):
+        _lib.check(_lib.load().tapclip_layernorm_f32(_ptr(xx), _ptr(g), _ptr(b), rows, d, _ptr(y), _stream_ptr(xx.device)))
+    return y
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, precision: str = "bf16") -> torch.Tensor:
+    """a[M,K] @ w[N,K].T + bias through the MFMA GEMM kernel (unit parity tests / roofline bench)."""
+    aa = a.detach().to(torch.float32).contiguous()
+    ww = w.detach().to(device=aa.device, dtype=torch.float32).contiguous()
+    M, K = aa.shape
+    N = ww.shape[0]
+    bb = None if bias is None else bias.detach().to(device=aa.device, dtype=torch.float32).contiguous()
+    lib = _lib.load()
+    nbytes = int(lib.tapclip_gemm_scratch_bytes(M, N, K))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=aa.device)
+    out = torch.empty(M, N, dtype=torch.float32, device=aa.device)
+    with torch.cuda.device(aa.device):
+        _lib.check(lib.tapclip_gemm_f32(_ptr(aa), _ptr(ww), _ptr(bb), M, N, K, _lib.PRECISIONS[precision], _ptr(out),
+                                        _ptr(scratch), nbytes, _stream_ptr(aa.device)))
+    return out

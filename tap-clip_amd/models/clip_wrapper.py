@@ -1,0 +1,222 @@
+"""MI355X drop-in for the reference's CLIP boundary (reference models/clip_wrapper.py:9-65).
+
+Same constructor and method surface -- `CLIPWrapper(model_name, pretrained_path, device)`,
+`.encode_image`, `.encode_text`, `.reset`, `.get_attention_map`, `.get_tokenizer`,
+`.get_preprocess`, `.model.transformer`, `.model.text_projection`, `.model.token_embedding`,
+`.attention_maps` -- but the encoder arithmetic runs in libtapclip.so (hand-written gfx950
+kernels) instead of open_clip.  The fp32 parameters are still held as frozen torch parameters
+under open_clip's names so `state_dict()` / `load_state_dict()` keep the reference's key layout
+(`clip.model.*`, reference test_cross_domain.py:43-61).
+
+Extra keyword-only knobs (defaults keep behaviour):
+  precision       "bf16" (fast) | "bf16x3" (split-bf16, ~fp32 accuracy: the parity mode)
+  attn_semantics  "intended": the text hook yields the head-mean softmax map [n,T,T] that the
+                  reference documents (clip_wrapper.py:35-36);
+                  "literal": what the reference's hook really captures -- `output[0]` of
+                  nn.MultiheadAttention is the attention OUTPUT, so `.mean(dim=1)` gives [n,D]
+                  (SURVEY.md section 0 item 1).
+  state_dict      pass weights directly instead of `pretrained_path`.
+"""
+from __future__ import annotations
+
+import zlib
+from typing import Callable, Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import engine
+from ..configs import ClipDims, get_config
+
+
+class _Bag(nn.Module):
+    """Parameter container mirroring one node of open_clip's module tree (names only)."""
+
+    def __getitem__(self, i: int):
+        kids = sorted((int(k), m) for k, m in self._modules.items() if k.isdigit())
+        return kids[i][1]
+
+    def __len__(self):
+        return sum(1 for k in self._modules if k.isdigit())
+
+
+class _TokenEmbedding(_Bag):
+    """`model.token_embedding` (used at reference models/prompt_learner.py:11-13,32-33)."""
+
+    def __init__(self, owner: "CLIPWrapper"):
+        super().__init__()
+        object.__setattr__(self, "_owner", owner)
+
+    @property
+    def embedding_dim(self) -> int:
+        return self.weight.shape[1]
+
+    def forward(self, tokens: torch.Tensor) -> torch.Tensor:
+        lead = tokens.shape[:-1]
+        flat = tokens.reshape(-1, tokens.shape[-1])
+        out = self._owner._text.embed_tokens(flat, add_pos=False)
+        return out.reshape(*lead, tokens.shape[-1], out.shape[-1])
+
+
+class _TextTransformer(_Bag):
+    """`model.transformer`: callable on [n,T,D] exactly as FullModel drives it (reference
+    models/model_wrapper.py:58,72) -- no positional embedding, no mask, no ln_final.  Every call
+    appends the last block's attention capture to `owner.attention_maps`, like the reference's
+    forward hook (clip_wrapper.py:29-40)."""
+
+    def __init__(self, owner: "CLIPWrapper"):
+        super().__init__()
+        object.__setattr__(self, "_owner", owner)
+
+    def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        own = self._owner
+        causal = False
+        if attn_mask is not None:
+            T = x.shape[1]
+            want = torch.full((T, T), float("-inf"), device=attn_mask.device).triu_(1)
+            if attn_mask.shape != want.shape or not torch.equal(attn_mask.to(want.dtype), want):
+                raise ValueError("only open_clip's causal attn_mask (or None) is supported")
+            causal = True
+        attn_mod = self.resblocks[-1].attn
+        user_hooks = len(attn_mod._forward_hooks) > 0
+        intended = own.attn_semantics == "intended"
+        r = own._text.forward(x, causal=causal, want_hidden=True, want_heads=user_hooks and intended,
+                              want_mean=intended, want_attn_out=not intended)
+        if intended:
+            own.attention_maps.append(r["attn_mean"])               # [n, T, T]
+        else:
+            own.attention_maps.append(r["attn_out"].mean(dim=1))    # [n, D]  (hook: output[0].mean(dim=1))
+        if user_hooks:  # fire hooks registered on resblocks[-1].attn the way nn.Module would
+            output = (r["attn_heads"] if intended else r["attn_out"], None)
+            for hook in list(attn_mod._forward_hooks.values()):
+                hook(attn_mod, (x,), output)
+        return r["hidden"]
+
+
+class _ClipModel(_Bag):
+    """Stands where open_clip's `CLIP` module stands (`CLIPWrapper.model`)."""
+
+    def __init__(self, owner: "CLIPWrapper"):
+        super().__init__()
+        object.__setattr__(self, "_owner", owner)
+
+    def encode_image(self, image: torch.Tensor, normalize: bool = False) -> torch.Tensor:
+        return self._owner._vision.encode_image(image, normalize=normalize)
+
+    def encode_text(self, text: torch.Tensor, normalize: bool = False) -> torch.Tensor:
+        own = self._owner
+        x = own._text.embed_tokens(text, add_pos=True)
+        hidden = own._text.forward(x, causal=True)["hidden"]
+        return own._text.pool_project(hidden, index=text.argmax(dim=-1), ln_final=True, normalize=normalize)
+
+
+class HashTokenizer:
+    """Deterministic stand-in for open_clip's BPE tokenizer (the BPE vocabulary file is not
+    available offline): SOT, one id per word (crc32 into the vocabulary), EOT = vocab-1 so that
+    `argmax` finds it like CLIP's EOT, zero padding to 77.  Returns [n,77] int64 like
+    `open_clip.get_tokenizer(name)(texts)`."""
+
+    def __init__(self, vocab: int = 49408, context_length: int = 77):
+        self.vocab, self.context_length = vocab, context_length
+
+    def __call__(self, texts, context_length: Optional[int] = None) -> torch.Tensor:
+        if isinstance(texts, str):
+            texts = [texts]
+        L = context_length or self.context_length
+        out = torch.zeros(len(texts), L, dtype=torch.long)
+        sot, eot = self.vocab - 2, self.vocab - 1
+        for i, t in enumerate(texts):
+            ids = [sot] + [1 + zlib.crc32(w.encode()) % (self.vocab - 3) for w in t.lower().split()][: L - 2] + [eot]
+            out[i, : len(ids)] = torch.tensor(ids)
+        return out
+
+
+def _make_preprocess(size: int) -> Callable:
+    """CLIP eval transform (resize shorter side bicubic -> centre crop -> normalise) on tensors /
+    PIL images, without torchvision."""
+    mean = torch.tensor([0.48145466, 0.4578275, 0.40821073]).view(3, 1, 1)
+    std = torch.tensor([0.26862954, 0.26130258, 0.27577711]).view(3, 1, 1)
+
+    def preprocess(img) -> torch.Tensor:
+        if not torch.is_tensor(img):
+            import numpy as np
+
+            arr = np.asarray(img.convert("RGB") if hasattr(img, "convert") else img)
+            img = torch.from_numpy(arr.copy()).permute(2, 0, 1)
+        x = img.float() / 255.0 if img.dtype == torch.uint8 else img.float()
+        _, h, w = x.shape
+        s = size / min(h, w)
+        nh, nw = max(size, round(h * s)), max(size, round(w * s))
+        x = torch.nn.functional.interpolate(x[None], size=(nh, nw), mode="bicubic", align_corners=False,
+                                            antialias=True)[0].clamp_(0, 1)
+        top, left = (nh - size) // 2, (nw - size) // 2
+        x = x[:, top: top + size, left: left + size]
+        return (x - mean) / std
+
+    return preprocess
+
+
+class CLIPWrapper(nn.Module):
+    def __init__(self, model_name: str = "ViT-B-32", pretrained_path: Optional[str] = "path/to/open_clip_pytorch_model.bin",
+                 device: str = "cuda", *, precision: str = "bf16", attn_semantics: str = "intended",
+                 state_dict: Optional[Dict[str, torch.Tensor]] = None, config: Optional[ClipDims] = None):
+        super().__init__()
+        if attn_semantics not in ("intended", "literal"):
+            raise ValueError(f"attn_semantics must be 'intended' or 'literal', got {attn_semantics!r}")
+        self.device = device
+        self.cfg = config or get_config(model_name)
+        self.precision = precision
+        self.attn_semantics = attn_semantics
+        if state_dict is None:
+            # a plain tensor state dict, as the reference loads (clip_wrapper.py:14); nothing is unpickled
+            state_dict = torch.load(pretrained_path, map_location="cpu", weights_only=True)
+        dev = torch.device(device)
+
+        # frozen fp32 parameters under open_clip's names (state_dict compatibility)
+        self.model = _ClipModel(self)
+        self._install(self.model, state_dict, dev)
+
+        # the HIP towers (weights packed to bf16 hi/lo inside the handles); strict=True semantics
+        self._vision = engine.VisionTower(self.cfg, state_dict, dev, precision)
+        self._text = engine.TextTower(self.cfg, state_dict, dev, precision)
+
+        self.attention_maps: List[torch.Tensor] = []
+        self.tokenizer = HashTokenizer(self.cfg.vocab, self.cfg.ctx)
+        self.preprocess = _make_preprocess(self.cfg.image_size)
+        self.eval()
+
+    def _install(self, root: _Bag, sd: Dict[str, torch.Tensor], dev: torch.device) -> None:
+        special = {"transformer": _TextTransformer, "token_embedding": _TokenEmbedding}
+        for key, t in sd.items():
+            node = root
+            parts = key.split(".")
+            for depth, name in enumerate(parts[:-1]):
+                if name not in node._modules:
+                    cls = special.get(name) if depth == 0 else None
+                    node.add_module(name, cls(self) if cls else _Bag())
+                node = node._modules[name]
+            node.register_parameter(parts[-1], nn.Parameter(t.detach().to(dev, torch.float32), requires_grad=False))
+
+    # ---- reference surface -----------------------------------------------------------------
+    def reset(self) -> None:
+        self.attention_maps.clear()
+
+    def encode_image(self, image_tensor: torch.Tensor) -> torch.Tensor:
+        return self.model.encode_image(image_tensor)
+
+    def encode_text(self, token_tensor: torch.Tensor) -> torch.Tensor:
+        self.reset()
+        return self.model.encode_text(token_tensor)
+
+    def get_attention_map(self) -> Optional[torch.Tensor]:
+        return self.attention_maps[-1] if self.attention_maps else None
+
+    def get_tokenizer(self):
+        return self.tokenizer
+
+    def get_preprocess(self):
+        return self.preprocess
+
+    def train(self, mode: bool = True):
+        # CLIP has no dropout / batch-norm: train() is numerically inert (reference train.py:91)
+        return super().train(mode)

@@ -1,0 +1,123 @@
+"""`FullModel`: image encode -> attribution over the prompt-prefixed text transformer -> prompt
+scaling -> text encode -> cosine logits (+ cross-entropy), on the MI355X towers.
+
+Drop-in for reference models/model_wrapper.py:12-100: same constructor, `forward(images,
+labels=None) -> {"logits"[, "loss", "loss_cls"]}`, `prompt_learner`, `logit_scale`, state-dict
+keys.  What changes is HOW the text side is evaluated:
+
+* collapsed text path (default).  In the reference the text features do not depend on the image:
+  per class it runs B identical batch-1 passes for the hook plus one batch-B pass on B identical
+  rows (model_wrapper.py:48-75).  That is exactly n_cls sequences x 2 passes and one
+  [B,E]x[E,n_cls] product (tests prove literal == collapsed), so this
+  module runs 2 text-tower launches per forward instead of n_cls*(B+1).
+  `collapse_text=False` replays the reference's loop nest verbatim (slow; parity checks only).
+* the attention capture follows the CLIP wrapper's `attn_semantics` ("intended" head-mean softmax
+  map vs the "literal" hook output, see clip_wrapper.py here).
+* multi-GPU: with `torch.distributed` initialised and `gather_images=True` every rank encodes its
+  own image shard and the L2-normalised embeddings are all-gathered (RCCL over xGMI) before the
+  logits, so every rank returns logits for the GLOBAL batch (rank-major row order).
+"""
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import engine
+from .attribution_monitor import AttributionMonitor
+from .prompt_adjustor import PromptAdjustor
+from .prompt_learner import PromptLearner
+
+
+class FullModel(nn.Module):
+    def __init__(self, class_names, clip_wrapper, prompt_len=5, attr_lambda=1.0, stab_lambda=0.1,
+                 adjustor_method='scale', class_specific=False, *, collapse_text: bool = True,
+                 gather_images: bool = False):
+        super().__init__()
+        self.clip = clip_wrapper
+        self.class_names = class_names
+        self.prompt_learner = PromptLearner(class_names, clip_wrapper, prompt_len, class_specific)
+        self.n_cls = len(class_names)
+        self.attribution_monitor = AttributionMonitor(prompt_len)
+        self.prompt_adjustor = PromptAdjustor(method=adjustor_method)
+        # stored, never used by forward -- as in the reference (model_wrapper.py:24-25)
+        self.attr_lambda = attr_lambda
+        self.stab_lambda = stab_lambda
+        # log(1/0.07): exp() = 14.2857, NOT the pretrained CLIP scale (model_wrapper.py:26)
+        self.logit_scale = nn.Parameter(torch.ones([]) * math.log(1 / 0.07))
+        self.collapse_text = collapse_text
+        self.gather_images = gather_images
+
+    # ---- text side -----------------------------------------------------------------------------
+    def text_features(self) -> torch.Tensor:
+        """L2-normalised text features [n_cls, E] (reference model_wrapper.py:47-75, collapsed)."""
+        pl, clip = self.prompt_learner, self.clip
+        P = pl.prompt_len
+        ctx, tok = pl.stacked_context().detach(), pl.stacked_tokens()
+        fused = self.prompt_adjustor.method == "scale"
+
+        # pass 1: only for the attention capture (model_wrapper.py:57-62)
+        clip.reset()
+        clip.model.transformer(engine.build_prompts(ctx, tok))
+        attn_map = clip.get_attention_map()
+        if attn_map.dim() == 2:
+            attn_map = attn_map.unsqueeze(1)  # per sample [1,D] -> [1,1,D] in the reference (:60-61)
+        attribution = self.attribution_monitor(attn_map)  # [n_cls, P] (or [n_cls, 1] literal)
+
+        # pass 2: adjusted prompt -> last token -> projection -> norm (model_wrapper.py:68-75)
+        if fused:
+            adjusted = engine.build_prompts(ctx, tok, attribution)
+        else:
+            adjusted = torch.cat([self.prompt_adjustor(ctx, attribution), tok], dim=1)
+        hidden = clip.model.transformer(adjusted)
+        self.last_attribution = attribution
+        return clip._text.pool_project(hidden, index=None, ln_final=False, normalize=True)
+
+    def _forward_literal(self, images: torch.Tensor) -> torch.Tensor:
+        """The reference loop nest as written (model_wrapper.py:47-83), on the HIP towers."""
+        pl, clip = self.prompt_learner, self.clip
+        P = pl.prompt_len
+        B = images.size(0)
+        raw = pl().detach()
+        image_feat = clip._vision.encode_image(images, normalize=True)
+        scale = float(self.logit_scale.detach().exp())
+        sims = []
+        for i, _name in enumerate(pl.context_bank.keys()):
+            ctx = raw[i, :P].unsqueeze(0).expand(B, -1, -1).contiguous()
+            cls_tok = raw[i, P:].unsqueeze(0).expand(B, -1, -1).contiguous()
+            attrs = []
+            for b in range(B):
+                clip.reset()
+                clip.model.transformer(engine.build_prompts(ctx[b: b + 1], cls_tok[b: b + 1]))
+                amap = clip.get_attention_map()
+                if amap.dim() == 2:
+                    amap = amap.unsqueeze(0)
+                attrs.append(self.attribution_monitor(amap))
+            attribution = torch.cat(attrs, dim=0)
+            hidden = clip.model.transformer(engine.build_prompts(ctx, cls_tok, attribution))
+            tf = clip._text.pool_project(hidden, normalize=True)                 # [B, E], rows identical
+            sims.append(scale * (image_feat * tf).sum(dim=-1, keepdim=True))
+        return torch.cat(sims, dim=1)
+
+    # ---- forward -------------------------------------------------------------------------------
+    def forward(self, images, labels=None):
+        if torch.is_grad_enabled() and labels is not None and any(p.requires_grad for p in self.prompt_learner.parameters()):
+            raise NotImplementedError(
+                "prompt-tuning backward (dX through the text tower) is not built yet: SURVEY.md section 8f row 1. "
+                "Call under torch.no_grad() for inference / evaluation.")
+        with torch.no_grad():
+            if not self.collapse_text:
+                logits = self._forward_literal(images)
+            else:
+                image_feat = self.clip._vision.encode_image(images, normalize=True)      # model_wrapper.py:40-41
+                if self.gather_images:
+                    from ..dist import all_gather_rows
+                    image_feat = all_gather_rows(image_feat)
+                text_feat = self.text_features()
+                logits = engine.logits(image_feat, text_feat, float(self.logit_scale.exp()))  # :79,83
+            outputs = {"logits": logits}
+            if labels is not None:
+                loss_cls = F.cross_entropy(logits, labels.to(logits.device))
+                outputs.update({"loss": loss_cls, "loss_cls": loss_cls})
+        return outputs

@@ -1,0 +1,193 @@
+"""CPU: the oracle (oracle/clip_ref.py, oracle/full_model_ref.py) against the golden vectors that
+oracle/make_golden.py produced by running the REFERENCE's own classes, and against independent
+implementations of the tower arithmetic (torch.nn.MultiheadAttention modules, HF transformers)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import tap_clip_amd  # noqa: F401
+from conftest import golden, rel_l2, rel_max
+from oracle import clip_ref, full_model_ref
+from tap_clip_amd import synth
+
+torch.set_num_threads(8)
+
+
+def _prompts_from_golden(g, cfg, sd):
+    ctx = torch.from_numpy(g["context"])
+    tok = sd["token_embedding.weight"][torch.from_numpy(g["token_ids"])]
+    return torch.cat([ctx, tok], dim=1)
+
+
+def test_attribution_matches_reference():
+    g = golden("attribution_monitor")
+    a = torch.from_numpy(g["attn_map"])
+    assert torch.allclose(full_model_ref.attribution_from_map(a, 16), torch.from_numpy(g["out_p16"]), atol=1e-7)
+    assert torch.equal(full_model_ref.attribution_from_map(a, 16, normalize=False), torch.from_numpy(g["out_p16_raw"]))
+    assert torch.allclose(full_model_ref.attribution_from_map(a, 5), torch.from_numpy(g["out_p5"]), atol=1e-7)
+    lit = full_model_ref.attribution_from_map(torch.from_numpy(g["literal_in"]), 5)
+    assert lit.shape == (4, 1) and torch.equal(lit, torch.from_numpy(g["literal_out_p5"]))  # == 1.0
+
+
+def test_adjust_matches_reference():
+    g = golden("prompt_adjustor")
+    p = torch.from_numpy(g["prompt"])
+    assert torch.equal(full_model_ref.adjust_scale(p, torch.from_numpy(g["attribution"])), torch.from_numpy(g["out"]))
+    assert torch.equal(p * torch.from_numpy(g["attribution_b1"]).unsqueeze(-1), torch.from_numpy(g["out_b1"]))
+
+
+@pytest.mark.parametrize("semantics", ["literal", "intended"])
+def test_fullmodel_tiny_matches_reference(semantics):
+    """logits / loss / attention capture of the reference FullModel (tiny towers, B=4, 3 classes)."""
+    g = golden(f"fullmodel_{semantics}_tiny")
+    cfg = clip_ref.CONFIGS["tiny"]
+    sd = synth.make_state_dict(cfg, seed=int(g["seed_weights"]))
+    images = synth.make_images(int(g["batch"]), cfg, int(g["seed_images"]))
+    prompts = _prompts_from_golden(g, cfg, sd)
+    assert torch.equal(prompts, torch.from_numpy(g["prompts"]))  # PromptLearner.forward concat order
+    labels = torch.from_numpy(g["labels"])
+    ref_logits = torch.from_numpy(g["logits"])
+    for fwd in (full_model_ref.forward_collapsed, full_model_ref.forward_literal):
+        out = fwd(images, prompts, int(g["prompt_len"]), sd, cfg, labels=labels, attn_semantics=semantics)
+        assert rel_max(out["logits"], ref_logits) < 2e-5, fwd.__name__
+        assert abs(float(out["loss"]) - float(g["loss"])) < 1e-5
+    if semantics == "intended":
+        out = full_model_ref.forward_collapsed(images, prompts, 5, sd, cfg, attn_semantics="intended")
+        assert rel_max(out["attn_map"], torch.from_numpy(g["attn_map"])) < 1e-5
+        assert rel_max(out["attribution"], torch.from_numpy(g["attribution"])) < 1e-5
+        assert torch.allclose(out["attn_map"].sum(-1), torch.ones(3, 82), atol=1e-5)
+    else:
+        out = full_model_ref.forward_collapsed(images, prompts, 5, sd, cfg, attn_semantics="literal")
+        assert torch.equal(out["attribution"], torch.ones(3, 1))  # softmax of one element
+
+
+def test_state_dict_key_layout_of_reference():
+    g = golden("fullmodel_intended_tiny")
+    keys = set(g["state_dict_keys"].tolist())
+    assert "logit_scale" in keys and "prompt_learner.token_embedding.weight" in keys
+    assert {f"prompt_learner.context_bank.{c}" for c in g["class_names"].tolist()} <= keys
+    assert "clip.model.transformer.resblocks.0.attn.in_proj_weight" in keys
+
+
+@pytest.mark.parametrize("tag", ["vision", "text"])
+def test_block_matches_torch_multihead_attention(tag):
+    """explicit-q/k/v block restatement == torch.nn.MultiheadAttention/LayerNorm/Linear/GELU modules"""
+    g = golden(f"block_{tag}")
+    d, heads, mlp, n, T = (int(g[k]) for k in ("d", "heads", "mlp", "n", "T"))
+    sd = {}
+    synth._tower(sd, "transformer.", d, 1, mlp, seed=int(g["seed_weights"]))
+    x = synth.normal([n, T, d], int(g["seed_x"]), f"block.{tag}.x")
+    taps = {}
+    y, p = clip_ref.block_forward(x, sd, "transformer.resblocks.0.", heads, want_probs=True, taps=taps)
+    assert rel_max(y, torch.from_numpy(g["out"])) < 1e-5
+    assert rel_max(taps["attn_out"], torch.from_numpy(g["attn_out"])) < 1e-5
+    assert rel_max(p.mean(dim=1), torch.from_numpy(g["probs_head_mean"])) < 1e-5
+    assert rel_max(p[:, 0, :8, :], torch.from_numpy(g["probs_head0_rows"])) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["ViT-B-16", "ViT-B-32"])
+def test_image_tower_regression(name):
+    g = golden(f"image_tower_{name}")
+    cfg = clip_ref.CONFIGS[name]
+    sd = synth.make_state_dict(cfg, seed=int(g["seed_weights"]), text=False)
+    images = synth.make_images(int(g["batch"]), cfg, int(g["seed_images"]))
+    with torch.no_grad():
+        emb = clip_ref.encode_image(images, sd, cfg)
+    assert rel_max(emb, torch.from_numpy(g["embeddings"])) < 1e-5
+
+
+@pytest.mark.parametrize("semantics", ["literal", "intended"])
+def test_fullmodel_vitb32_cfg1(semantics):
+    """BASELINE.json configs[0] (ViT-B/32, batch 8, 10 classes, P=5): reference FullModel logits, produced
+    by its literal loop nest, equal the oracle's collapsed form."""
+    g = golden(f"fullmodel_{semantics}_vitb32")
+    cfg = clip_ref.CONFIGS["ViT-B-32"]
+    sd = synth.make_state_dict(cfg, seed=int(g["seed_weights"]))
+    images = synth.make_images(int(g["batch"]), cfg, int(g["seed_images"]))
+    prompts = _prompts_from_golden(g, cfg, sd)
+    with torch.no_grad():
+        out = full_model_ref.forward_collapsed(images, prompts, int(g["prompt_len"]), sd, cfg,
+                                               labels=torch.from_numpy(g["labels"]), attn_semantics=semantics)
+    assert rel_max(out["logits"], torch.from_numpy(g["logits"])) < 1e-4
+    assert abs(float(out["loss"]) - float(g["loss"])) < 1e-4
+
+
+def test_towers_match_hf_transformers_clip():
+    """Independent second implementation of the tower arithmetic: HF `transformers` CLIP built from a
+    config (no hub access), weights copied from a seeded open_clip-layout state dict."""
+    transformers = pytest.importorskip("transformers")
+    cfg = clip_ref.CONFIGS["tiny"]
+    sd = synth.make_state_dict(cfg, seed=4)
+    v, t = cfg.vision, cfg.text
+    hf_cfg = transformers.CLIPConfig(
+        vision_config=dict(hidden_size=v.width, intermediate_size=v.mlp, num_hidden_layers=v.layers,
+                           num_attention_heads=v.heads, image_size=cfg.image_size, patch_size=cfg.patch,
+                           hidden_act="gelu", projection_dim=cfg.embed_dim, attn_implementation="eager"),
+        text_config=dict(hidden_size=t.width, intermediate_size=t.mlp, num_hidden_layers=t.layers,
+                         num_attention_heads=t.heads, vocab_size=cfg.vocab, max_position_embeddings=cfg.ctx,
+                         hidden_act="gelu", projection_dim=cfg.embed_dim, eos_token_id=cfg.vocab - 1,
+                         attn_implementation="eager"),
+        projection_dim=cfg.embed_dim)
+    model = transformers.CLIPModel(hf_cfg).eval()
+    hsd = model.state_dict()
+
+    def put(k, val):
+        assert hsd[k].shape == val.shape, (k, hsd[k].shape, val.shape)
+        hsd[k] = val.clone()
+
+    def tower(src, dst, layers, d):
+        for i in range(layers):
+            s, o = f"{src}resblocks.{i}.", f"{dst}.encoder.layers.{i}."
+            w, b = sd[s + "attn.in_proj_weight"], sd[s + "attn.in_proj_bias"]
+            for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):
+                put(o + f"self_attn.{nm}.weight", w[j * d:(j + 1) * d])
+                put(o + f"self_attn.{nm}.bias", b[j * d:(j + 1) * d])
+            put(o + "self_attn.out_proj.weight", sd[s + "attn.out_proj.weight"])
+            put(o + "self_attn.out_proj.bias", sd[s + "attn.out_proj.bias"])
+            for a, bb in (("ln_1", "layer_norm1"), ("ln_2", "layer_norm2")):
+                put(o + bb + ".weight", sd[s + a + ".weight"]); put(o + bb + ".bias", sd[s + a + ".bias"])
+            for a, bb in (("c_fc", "fc1"), ("c_proj", "fc2")):
+                put(o + f"mlp.{bb}.weight", sd[s + f"mlp.{a}.weight"]); put(o + f"mlp.{bb}.bias", sd[s + f"mlp.{a}.bias"])
+
+    tower("visual.transformer.", "vision_model", v.layers, v.width)
+    tower("transformer.", "text_model", t.layers, t.width)
+    put("vision_model.embeddings.patch_embedding.weight", sd["visual.conv1.weight"])
+    put("vision_model.embeddings.class_embedding", sd["visual.class_embedding"])
+    put("vision_model.embeddings.position_embedding.weight", sd["visual.positional_embedding"])
+    put("vision_model.pre_layrnorm.weight", sd["visual.ln_pre.weight"]); put("vision_model.pre_layrnorm.bias", sd["visual.ln_pre.bias"])
+    put("vision_model.post_layernorm.weight", sd["visual.ln_post.weight"]); put("vision_model.post_layernorm.bias", sd["visual.ln_post.bias"])
+    put("visual_projection.weight", sd["visual.proj"].t())
+    put("text_model.embeddings.token_embedding.weight", sd["token_embedding.weight"])
+    put("text_model.embeddings.position_embedding.weight", sd["positional_embedding"])
+    put("text_model.final_layer_norm.weight", sd["ln_final.weight"]); put("text_model.final_layer_norm.bias", sd["ln_final.bias"])
+    put("text_projection.weight", sd["text_projection"].t())
+    model.load_state_dict(hsd, strict=True)
+
+    images = synth.make_images(3, cfg, 9)
+    tokens = torch.zeros(4, cfg.ctx, dtype=torch.long)
+    for i in range(4):
+        L = 4 + i
+        tokens[i, 0] = cfg.vocab - 2
+        tokens[i, 1:1 + L] = synth.integers([L], 3, f"hf.{i}", cfg.vocab - 3) + 1
+        tokens[i, 1 + L] = cfg.vocab - 1
+    with torch.no_grad():
+        img_hf = model.get_image_features(pixel_values=images)
+        txt_hf = model.get_text_features(input_ids=tokens)
+        img_hf = getattr(img_hf, "pooler_output", img_hf)
+        txt_hf = getattr(txt_hf, "pooler_output", txt_hf)
+        img = clip_ref.encode_image(images, sd, cfg)
+        txt = clip_ref.encode_text(tokens, sd, cfg)
+    assert rel_max(img, img_hf) < 1e-5
+    assert rel_max(txt, txt_hf) < 1e-5
+
+
+def test_emulated_bf16_oracle_is_close_to_fp32():
+    """The bf16-operand emulation stays within bf16's expected band of the fp32 oracle."""
+    cfg = clip_ref.CONFIGS["tiny"]
+    sd = synth.make_state_dict(cfg, seed=2)
+    images = synth.make_images(4, cfg, 0)
+    a = clip_ref.encode_image(images, sd, cfg, normalize=True)
+    b = clip_ref.encode_image(images, sd, cfg, emulate="bf16", normalize=True)
+    assert 1e-5 < rel_l2(b, a) < 3e-2
