@@ -203,7 +203,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import clip_ref  # the CPU port, timed as the baseline only
 
-        ncpu = os.cpu_count() or 1
+        # the cores this process may actually use (the GPU box gives one GPU's CPU share, not os.cpu_count())
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        ncpu = min(ncpu, int(os.environ.get("TAPCLIP_CPU_THREADS", "16")))
         torch.set_num_threads(ncpu)
         sample = images[:32].cpu()
         sd_v = {k: v for k, v in sd.items() if k.startswith("visual.")}

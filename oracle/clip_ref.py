@@ -148,7 +148,13 @@ def block_forward(
     if attn_mask is not None:
         s = s + attn_mask
     p = torch.softmax(s, dim=-1)
-    o = _rb(p, emulate) @ _rb(v, emulate)  # [n, H, T, hd]
+    if emulate:
+        # the attention kernel rounds the UN-normalised exp(s - max) to bf16 for the PV product and
+        # divides the 64 outputs by the fp32 row sum afterwards (same function, other rounding point)
+        e = torch.exp(s - s.amax(dim=-1, keepdim=True))
+        o = (_rb(e, emulate) @ _rb(v, emulate)) / e.sum(dim=-1, keepdim=True)
+    else:
+        o = p @ v  # [n, H, T, hd]
     o = o.transpose(1, 2).reshape(n, T, D)
     if taps is not None:
         taps["probs"] = p

@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   uint8_t* Kl = smem + 2 * TILE;       // SPLIT only
   uint8_t* Vl = smem + 3 * TILE;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int T = a.T, D = a.D;
   const int seq = blockIdx.x / a.H, head = blockIdx.x - seq * a.H;
@@ -50,42 +51,69 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   const int64_t ld = 3 * (int64_t)D;
   const int qcol = head * 64, kcol = D + head * 64, vcol = 2 * D + head * 64;
 
-  // ---- stage K (swizzled) and V (plain) of this head into LDS; rows >= T are zero
-  for (int c = tid; c < KEYS * 8; c += 256) {
-    const int key = c >> 3, kc = c & 7;
-    uint4 kv = make_uint4(0, 0, 0, 0), vv = kv, kvl = kv, vvl = kv;
-    if (key < T) {
-      const int64_t base = (row0 + key) * ld + kc * 8;
-      kv = *reinterpret_cast<const uint4*>(a.qkv_hi + base + kcol);
-      vv = *reinterpret_cast<const uint4*>(a.qkv_hi + base + vcol);
+  // ---- Q fragments of every q-tile this wave owns, issued BEFORE the K/V staging so their latency
+  // overlaps it.  B[k = d = 32*s + 8*g + j][col = q]; queries past T are clamped (never stored).
+  constexpr int QT_MAX = (NKT + 3) / 4;
+  const int n_qt = (T + 15) >> 4;
+  bf16x8_t qh[QT_MAX][2], ql[SPLIT ? QT_MAX : 1][2];
+#pragma unroll
+  for (int t = 0; t < QT_MAX; ++t) {
+    int qc = (wave + 4 * t) * 16 + r;
+    if (qc >= T) qc = T - 1;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int64_t off = (row0 + qc) * ld + qcol + 32 * s + 8 * g;
+      qh[t][s] = *reinterpret_cast<const bf16x8_t*>(a.qkv_hi + off);
+      if (SPLIT) ql[t][s] = *reinterpret_cast<const bf16x8_t*>(a.qkv_lo + off);
+    }
+  }
+
+  // ---- stage K (swizzled) and V (plain) of this head into LDS; rows >= T are zero.  The trip count
+  // is a compile-time constant so all the global loads are in flight together.
+  constexpr int N_IT = KEYS * 8 / 256;
+  {
+    uint4 kv[N_IT], vv[N_IT], kvl[SPLIT ? N_IT : 1], vvl[SPLIT ? N_IT : 1];
+#pragma unroll
+    for (int it = 0; it < N_IT; ++it) {
+      const int c = tid + 256 * it;
+      const int key = c >> 3, kc = c & 7;
+      kv[it] = make_uint4(0, 0, 0, 0);
+      vv[it] = kv[it];
       if (SPLIT) {
-        kvl = *reinterpret_cast<const uint4*>(a.qkv_lo + base + kcol);
-        vvl = *reinterpret_cast<const uint4*>(a.qkv_lo + base + vcol);
+        kvl[it] = kv[it];
+        vvl[it] = kv[it];
+      }
+      if (key < T) {
+        const int64_t base = (row0 + key) * ld + kc * 8;
+        kv[it] = *reinterpret_cast<const uint4*>(a.qkv_hi + base + kcol);
+        vv[it] = *reinterpret_cast<const uint4*>(a.qkv_hi + base + vcol);
+        if (SPLIT) {
+          kvl[it] = *reinterpret_cast<const uint4*>(a.qkv_lo + base + kcol);
+          vvl[it] = *reinterpret_cast<const uint4*>(a.qkv_lo + base + vcol);
+        }
       }
     }
-    const int ko = key * 128 + ((kc ^ (key & 7)) << 4);
-    const int vo = key * 128 + (kc << 4);
-    *reinterpret_cast<uint4*>(Kh + ko) = kv;
-    *reinterpret_cast<uint4*>(Vh + vo) = vv;
-    if (SPLIT) {
-      *reinterpret_cast<uint4*>(Kl + ko) = kvl;
-      *reinterpret_cast<uint4*>(Vl + vo) = vvl;
+#pragma unroll
+    for (int it = 0; it < N_IT; ++it) {
+      const int c = tid + 256 * it;
+      const int key = c >> 3, kc = c & 7;
+      const int ko = key * 128 + ((kc ^ (key & 7)) << 4);
+      const int vo = key * 128 + (kc << 4);
+      *reinterpret_cast<uint4*>(Kh + ko) = kv[it];
+      *reinterpret_cast<uint4*>(Vh + vo) = vv[it];
+      if (SPLIT) {
+        *reinterpret_cast<uint4*>(Kl + ko) = kvl[it];
+        *reinterpret_cast<uint4*>(Vl + vo) = vvl[it];
+      }
     }
   }
   __syncthreads();
 
-  const int n_qt = (T + 15) >> 4;
-  for (int qt = wave; qt < n_qt; qt += 4) {
-    const int qi = qt * 16 + r;             // this lane's query (column of S^T)
-    const int qrow = qi < T ? qi : T - 1;   // clamp: padded queries are computed, never stored
-    // Q fragments: B[k = d = 32*s + 8*g + j][col = q]
-    bf16x8_t qh[2], ql[2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int64_t off = (row0 + qrow) * ld + qcol + 32 * s + 8 * g;
-      qh[s] = *reinterpret_cast<const bf16x8_t*>(a.qkv_hi + off);
-      if (SPLIT) ql[s] = *reinterpret_cast<const bf16x8_t*>(a.qkv_lo + off);
-    }
+  for (int t = 0; t < QT_MAX; ++t) {
+    const int qt = wave + 4 * t;
+    if (qt >= n_qt) break;       // wave-uniform
+    const int qi = qt * 16 + r;  // this lane's query (column of S^T)
 
     // ---- S^T = K . Q^T
     f32x4_t sc[NKT];
@@ -97,44 +125,46 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
       for (int s = 0; s < 2; ++s) {
         const int off = key * 128 + (((4 * s + g) ^ (key & 7)) << 4);
         const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Kh + off);
-        sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qh[s], sc[kt], 0, 0, 0);
+        sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qh[t][s], sc[kt], 0, 0, 0);
         if (SPLIT) {
           const bf16x8_t kfl = *reinterpret_cast<const bf16x8_t*>(Kl + off);
-          sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfl, qh[s], sc[kt], 0, 0, 0);
-          sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, ql[s], sc[kt], 0, 0, 0);
+          sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfl, qh[t][s], sc[kt], 0, 0, 0);
+          sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, ql[t][s], sc[kt], 0, 0, 0);
         }
       }
     }
 
-    // ---- mask + softmax over keys (lane-local + 2 shuffles)
+    // ---- mask + softmax over keys (lane-local + 2 shuffles).  Only key tiles that reach past T (or,
+    // causal, past the diagonal) need the mask.  P stays un-normalised (largest element 1); 1/sum is
+    // applied to the 16 O values, and to P only where it is written back.
     float mx = -INFINITY;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
+    for (int kt = 0; kt < NKT; ++kt) {
+      if ((kt * 16 + 15 >= T) || a.causal) {  // wave-uniform
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int key = kt * 16 + 4 * g + e;
-        const bool dead = key >= T || (a.causal && key > qi);
-        if (dead) sc[kt][e] = -INFINITY;
-        mx = fmaxf(mx, sc[kt][e]);
+        for (int e = 0; e < 4; ++e) {
+          const int key = kt * 16 + 4 * g + e;
+          if (key >= T || (a.causal && key > qi)) sc[kt][e] = -INFINITY;
+        }
       }
+      mx = fmaxf(mx, fmaxf(fmaxf(sc[kt][0], sc[kt][1]), fmaxf(sc[kt][2], sc[kt][3])));
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float LOG2E = 1.44269504088896340736f;
+    const float nmx = -mx * LOG2E;
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float p = __expf(sc[kt][e] - mx);  // exp(-inf) = 0 for masked keys
+        const float p = __builtin_amdgcn_exp2f(fmaf(sc[kt][e], LOG2E, nmx));  // exp(s - max); 0 when masked
         sc[kt][e] = p;
         sum += p;
       }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) sc[kt][e] *= inv;
 
     // ---- optional probability write-back: probs[seq, head, q, key]
     if (a.probs != nullptr && qi < T) {
@@ -144,7 +174,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int key = kt * 16 + 4 * g + e;
-          if (key < T) prow[key] = sc[kt][e];
+          if (key < T) prow[key] = sc[kt][e] * inv;
         }
     }
 
@@ -195,8 +225,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         bf16_t h[4], l[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if (SPLIT) split_bf(oc[dt][e], h[e], l[e]);
-          else h[e] = f2bf(oc[dt][e]);
+          if (SPLIT) split_bf(oc[dt][e] * inv, h[e], l[e]);
+          else h[e] = f2bf(oc[dt][e] * inv);
         }
         uint2 phk;
         phk.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);

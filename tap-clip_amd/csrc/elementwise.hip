@@ -124,6 +124,7 @@ __global__ void scale_copy_kernel(const float* __restrict__ src, int64_t n, int6
 // models/clip_wrapper.py:47 + models/model_wrapper.py:41).  text: token -1, text_projection, norm
 // (reference models/model_wrapper.py:73-75); encode_text: EOT row, ln_final (clip_wrapper.py:49-51).
 // One workgroup per output row; fp32 FMA throughout (0.8 MFLOP per row).
+template <int NE>  // outputs per thread: E <= 256 * NE
 __global__ __launch_bounds__(256) void pool_project_kernel(const float* __restrict__ src, int tokens, int K,
                                                            const int64_t* __restrict__ index, int fixed_token,
                                                            const float* __restrict__ ln_g,
@@ -162,21 +163,33 @@ __global__ __launch_bounds__(256) void pool_project_kernel(const float* __restri
     for (int c = tid; c < K; c += 256) row[c] = (row[c] - mean) * rstd * ln_g[c] + ln_b[c];
     __syncthreads();
   }
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};  // E <= 1024
-  for (int k = 0; k < K; ++k) {
-    const float xv = row[k];
-    const float* pr = proj + (int64_t)k * E;
+  // projection: 8 k-steps of loads are issued together (unconditional, clamped column index) so the
+  // L2 latency is paid once per 8 steps instead of once per step
+  float acc[NE];
+  int ec[NE];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int e = tid + 256 * j;
-      if (e < E) acc[j] = fmaf(xv, pr[e], acc[j]);
+  for (int j = 0; j < NE; ++j) {
+    acc[j] = 0.f;
+    ec[j] = tid + 256 * j < E ? tid + 256 * j : E - 1;
+  }
+  for (int k0 = 0; k0 < K; k0 += 8) {
+    float pv[8][NE];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int j = 0; j < NE; ++j) pv[u][j] = proj[(int64_t)(k0 + u) * E + ec[j]];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float xv = row[k0 + u];
+#pragma unroll
+      for (int j = 0; j < NE; ++j) acc[j] = fmaf(xv, pv[u][j], acc[j]);
     }
   }
   float scale = 1.f;
   if (normalize) {
     float ss = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NE; ++j)
       if (tid + 256 * j < E) ss += acc[j] * acc[j];
     ss = wave_sum(ss);
     if (lane == 0) red[4 + wave] = ss;
@@ -184,7 +197,7 @@ __global__ __launch_bounds__(256) void pool_project_kernel(const float* __restri
     scale = 1.0f / sqrtf(red[4] + red[5] + red[6] + red[7]);
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NE; ++j) {
     const int e = tid + 256 * j;
     if (e < E) out[n * E + e] = acc[j] * scale;
   }
@@ -303,9 +316,15 @@ hipError_t launch_scale_copy(const float* src, int64_t n, int64_t scale_n, float
 hipError_t launch_pool_project(const float* src, int64_t n, int32_t tokens, int32_t K, const int64_t* index,
                                int32_t fixed_token, const float* ln_g, const float* ln_b, const float* proj,
                                int32_t E, int32_t normalize, float* out, hipStream_t s) {
-  if (E > 1024 || K > 8192) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(pool_project_kernel, dim3((unsigned)n), dim3(256), (K + 8) * sizeof(float), s, src, tokens, K,
-                     index, fixed_token, ln_g, ln_b, proj, E, normalize, out);
+  if (E > 1024 || K > 8192 || K % 8 != 0) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)n), block(256);
+  const size_t sh = (K + 8) * sizeof(float);
+  switch ((E + 255) / 256) {
+    case 1: hipLaunchKernelGGL((pool_project_kernel<1>), grid, block, sh, s, src, tokens, K, index, fixed_token, ln_g, ln_b, proj, E, normalize, out); break;
+    case 2: hipLaunchKernelGGL((pool_project_kernel<2>), grid, block, sh, s, src, tokens, K, index, fixed_token, ln_g, ln_b, proj, E, normalize, out); break;
+    case 3: hipLaunchKernelGGL((pool_project_kernel<3>), grid, block, sh, s, src, tokens, K, index, fixed_token, ln_g, ln_b, proj, E, normalize, out); break;
+    default: hipLaunchKernelGGL((pool_project_kernel<4>), grid, block, sh, s, src, tokens, K, index, fixed_token, ln_g, ln_b, proj, E, normalize, out); break;
+  }
   return hipGetLastError();
 }
 

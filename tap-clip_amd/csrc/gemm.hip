@@ -12,6 +12,8 @@
 // fragment reads of 16 different rows at one k-chunk spread over 8 slots (guide T2).
 // bf16x3 (SPLIT): the K loop runs three segments (A_hi,W_hi), (A_lo,W_hi), (A_hi,W_lo) into the same
 // accumulators.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -22,43 +24,32 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 
-struct Stage {
-  uint4 a[4];
-  uint4 w[4];
-};
+// Per-thread staging slots: 4 x 16 B of the A tile and 4 x 16 B of the W tile (chunk c = tid + 256 i:
+// row = c >> 3, 16-byte k-chunk = c & 7).  Kept as plain register arrays indexed by unrolled constants
+// (a struct passed by reference was demoted to scratch memory by hipcc and serialised every load).
+#define TAPCLIP_STAGE_LOAD(KT_IDX)                                                              \
+  {                                                                                             \
+    int seg_ = 0, kk_ = (KT_IDX);                                                               \
+    if (SPLIT) {                                                                                \
+      seg_ = kk_ / KT1;                                                                         \
+      kk_ -= seg_ * KT1;                                                                        \
+    }                                                                                           \
+    const bf16_t* Ap_ = (SPLIT && seg_ == 1) ? g.A_lo : g.A_hi;                                 \
+    const bf16_t* Wp_ = (SPLIT && seg_ == 2) ? g.W_lo : g.W_hi;                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                          \
+      ra[i_] = *reinterpret_cast<const uint4*>(Ap_ + a_off[i_] + kk_ * BK);                     \
+      rw[i_] = *reinterpret_cast<const uint4*>(Wp_ + w_off[i_] + kk_ * BK);                     \
+    }                                                                                           \
+  }
 
-template <bool SPLIT>
-__device__ __forceinline__ void stage_load(const GemmArgs& g, int64_t m0, int n0, int kt, int KT1, int tid,
-                                           Stage& st) {
-  int seg = 0, kk = kt;
-  if (SPLIT) {
-    seg = kt / KT1;
-    kk = kt - seg * KT1;
+#define TAPCLIP_STAGE_WRITE(BUF)                                                                \
+  {                                                                                             \
+    uint8_t* bA_ = smem + (BUF) * 2 * TILE_BYTES;                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                          \
+      *reinterpret_cast<uint4*>(bA_ + lds_off[i_]) = ra[i_];                                    \
+      *reinterpret_cast<uint4*>(bA_ + TILE_BYTES + lds_off[i_]) = rw[i_];                       \
+    }                                                                                           \
   }
-  const bf16_t* Ap = (SPLIT && seg == 1) ? g.A_lo : g.A_hi;
-  const bf16_t* Wp = (SPLIT && seg == 2) ? g.W_lo : g.W_hi;
-  const int k0 = kk * BK;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = tid + 256 * i;
-    const int row = c >> 3, kc = c & 7;
-    int64_t m = m0 + row;
-    if (m >= g.M) m = g.M - 1;  // clamp: rows past M are computed but never stored
-    st.a[i] = *reinterpret_cast<const uint4*>(Ap + m * g.lda + k0 + kc * 8);
-    st.w[i] = *reinterpret_cast<const uint4*>(Wp + (int64_t)(n0 + row) * g.K + k0 + kc * 8);
-  }
-}
-
-__device__ __forceinline__ void stage_write(uint8_t* bufA, uint8_t* bufW, int tid, const Stage& st) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = tid + 256 * i;
-    const int row = c >> 3, kc = c & 7;
-    const int off = row * 128 + ((kc ^ (row & 7)) << 4);
-    *reinterpret_cast<uint4*>(bufA + off) = st.a[i];
-    *reinterpret_cast<uint4*>(bufW + off) = st.w[i];
-  }
-}
 
 template <int EPI, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
@@ -91,17 +82,32 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  Stage st;
-  stage_load<SPLIT>(g, m0, n0, 0, KT1, tid, st);
-  stage_write(smem, smem + TILE_BYTES, tid, st);
+  // per-thread staging addresses (element offsets into A / W, byte offsets into an LDS tile)
+  int64_t a_off[4], w_off[4];
+  int lds_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i;
+    const int row = c >> 3, kc = c & 7;
+    int64_t m = m0 + row;
+    if (m >= g.M) m = g.M - 1;  // clamp: rows past M are computed but never stored
+    a_off[i] = m * g.lda + kc * 8;
+    w_off[i] = (int64_t)(n0 + row) * g.K + kc * 8;
+    lds_off[i] = row * 128 + ((kc ^ (row & 7)) << 4);
+  }
+  uint4 ra[4], rw[4];
+  TAPCLIP_STAGE_LOAD(0)
+  TAPCLIP_STAGE_WRITE(0)
   __syncthreads();
 
   for (int kt = 0; kt < KT; ++kt) {
     const int cur = kt & 1;
     const uint8_t* bufA = smem + cur * 2 * TILE_BYTES;
     const uint8_t* bufW = bufA + TILE_BYTES;
-    const bool more = kt + 1 < KT;
-    if (more) stage_load<SPLIT>(g, m0, n0, kt + 1, KT1, tid, st);
+    // prefetch the next K tile into registers (the last iteration re-reads its own tile: harmless,
+    // keeps the loop body branch-free around the loads)
+    const int ktn = kt + 1 < KT ? kt + 1 : kt;
+    TAPCLIP_STAGE_LOAD(ktn)
 
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -124,10 +130,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
     }
 
-    if (more) {
-      uint8_t* nA = smem + (cur ^ 1) * 2 * TILE_BYTES;
-      stage_write(nA, nA + TILE_BYTES, tid, st);
-    }
+    TAPCLIP_STAGE_WRITE(cur ^ 1)  // the other buffer: its last readers passed the previous barrier
     __syncthreads();
   }
 
@@ -212,9 +215,19 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
+hipError_t launch_gemm256(const GemmArgs& a, int epilogue, bool split, hipStream_t s);  // gemm256.hip
+
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, bool split, hipStream_t s) {
   if (a.M <= 0 || a.N % BN != 0 || a.K % BK != 0 || a.K <= 0) return hipErrorInvalidValue;
   if ((a.lda % 8) != 0 || (a.ldo % 4) != 0) return hipErrorInvalidValue;
+  // large problems (the image tower: M = 50 432): 256-row tiles staged by LDS-DMA; small ones (the text
+  // tower: M = 6 045) keep 128 x 128 tiles so the grid still covers the 256 CUs
+  // TAPCLIP_GEMM_TILE=128|256 pins the choice (tests exercise both kernels on the same problem)
+  static const int forced = [] {
+    const char* e = getenv("TAPCLIP_GEMM_TILE");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 256 || (forced != 128 && a.M >= 8192)) return launch_gemm256(a, epilogue, split, s);
 #define TAPCLIP_GEMM_CASE(E)                                      \
   case E:                                                         \
     return split ? launch_t<E, true>(a, s) : launch_t<E, false>(a, s);

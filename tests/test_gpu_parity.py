@@ -62,6 +62,33 @@ def test_gemm(eng, M, N, K):
     assert rel_max(y1, ref16.float()) < 1e-5, "bf16 GEMM must equal the product of bf16-rounded operands"
 
 
+@pytest.mark.parametrize("tile,bn", [("256", "128"), ("256", "256")])
+def test_gemm_large_tile_kernel(tile, bn):
+    """The 256-row LDS-DMA kernel (used for the image tower's M = 50 432) on a ragged M, in a fresh
+    process so the tile choice can be pinned through the environment."""
+    import os, subprocess, sys
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+import tap_clip_amd
+from tap_clip_amd import engine, synth
+M, N, K = 8192 + 77, 512, 192
+a = synth.normal([M, K], 2, "g.a"); w = synth.normal([N, K], 2, "g.w", K ** -0.5); b = synth.normal([N], 2, "g.b", 0.1)
+ref = a.double() @ w.double().t() + b.double()
+y3 = engine.gemm(a.cuda(), w.cuda(), b.cuda(), "bf16x3").cpu().double()
+assert float((y3 - ref).abs().max() / ref.abs().max()) < 1e-4, "bf16x3"
+ref16 = a.bfloat16().double() @ w.bfloat16().double().t() + b.double()
+y1 = engine.gemm(a.cuda(), w.cuda(), b.cuda(), "bf16").cpu().double()
+assert float((y1 - ref16).abs().max() / ref16.abs().max()) < 1e-5, "bf16"
+eye = torch.eye(128); wa = (torch.arange(256 * 128, dtype=torch.float32).reshape(256, 128) %% 251) - 125.0
+assert torch.equal(engine.gemm(eye.cuda(), wa.cuda(), None, "bf16").cpu(), wa.t())
+print("ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TAPCLIP_GEMM_TILE=tile, TAPCLIP_GEMM_BN=bn)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_gemm_identity_asymmetric(eng):
     """A = I with an asymmetric W catches a transposed C/D fragment map (guide section 3)."""
     K = N = 128

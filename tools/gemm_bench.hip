@@ -1,0 +1,92 @@
+// Micro-benchmark of the MFMA GEMM kernels at the image tower's shapes (development tool; not part
+// of the library).  Build: make -C tools.  Usage: tools/gemm_bench [iters]
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../tap-clip_amd/csrc/kernels.h"
+
+using namespace tapclip;
+
+#define CK(x)                                                                      \
+  do {                                                                             \
+    hipError_t e_ = (x);                                                           \
+    if (e_ != hipSuccess) {                                                        \
+      printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      exit(1);                                                                     \
+    }                                                                              \
+  } while (0)
+
+static uint16_t f2bf_host(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  u += 0x7FFF + ((u >> 16) & 1);
+  return (uint16_t)(u >> 16);
+}
+
+static bf16_t* rand_bf16(size_t n, uint64_t seed, float scale) {
+  std::vector<uint16_t> h(n);
+  uint64_t s = seed * 0x9E3779B97F4A7C15ull + 12345;
+  for (size_t i = 0; i < n; ++i) {
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    float u = (float)((s >> 40) & 0xFFFFFF) / 8388608.0f - 1.0f;  // [-1, 1)
+    h[i] = f2bf_host(u * scale);
+  }
+  bf16_t* d;
+  CK(hipMalloc(&d, n * 2));
+  CK(hipMemcpy(d, h.data(), n * 2, hipMemcpyHostToDevice));
+  return d;
+}
+
+int main(int argc, char** argv) {
+  const int iters = argc > 1 ? atoi(argv[1]) : 20;
+  const int64_t M = argc > 2 ? atoll(argv[2]) : 50432;
+  struct Shape { const char* name; int N, K, epi; };
+  const Shape shapes[] = {
+      {"qkv      N2304 K768  bias->bf16 ", 2304, 768, EPI_BIAS_BF16},
+      {"out_proj N768  K768  resid f32  ", 768, 768, EPI_BIAS_RESID_F32},
+      {"fc_gelu  N3072 K768  gelu->bf16 ", 3072, 768, EPI_BIAS_GELU_BF16},
+      {"proj     N768  K3072 resid f32  ", 768, 3072, EPI_BIAS_RESID_F32},
+      {"qkv-like N2304 K3072 bias->bf16 ", 2304, 3072, EPI_BIAS_BF16},   // slope/intercept probe
+      {"qkv-like N2304 K1536 bias->bf16 ", 2304, 1536, EPI_BIAS_BF16},
+  };
+  bf16_t* A = rand_bf16((size_t)M * 3072, 1, 1.0f);
+  bf16_t* W = rand_bf16((size_t)3072 * 3072, 2, 0.03f);
+  float* bias;
+  CK(hipMalloc(&bias, 3072 * 4));
+  CK(hipMemset(bias, 0, 3072 * 4));
+  bf16_t* obf;
+  CK(hipMalloc(&obf, (size_t)M * 3072 * 2));
+  float* of32;
+  CK(hipMalloc(&of32, (size_t)M * 768 * 4));
+  CK(hipMemset(of32, 0, (size_t)M * 768 * 4));
+  hipStream_t s;
+  CK(hipStreamCreate(&s));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (const Shape& sh : shapes) {
+    GemmArgs g;
+    g.A_hi = A; g.A_lo = nullptr; g.lda = sh.K;
+    g.W_hi = W; g.W_lo = nullptr;
+    g.bias = bias;
+    g.M = M; g.N = sh.N; g.K = sh.K;
+    g.out_hi = obf; g.out_lo = nullptr; g.out_f32 = of32; g.ldo = sh.N;
+    g.add_table = nullptr; g.rows_per_group = 0; g.act = 0;
+    for (int i = 0; i < 3; ++i) CK(launch_gemm(g, sh.epi, false, s));
+    CK(hipStreamSynchronize(s));
+    CK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) CK(launch_gemm(g, sh.epi, false, s));
+    CK(hipEventRecord(e1, s));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = 1e3 * ms / iters;
+    const double tf = 2.0 * M * sh.N * sh.K / (us * 1e-6) / 1e12;
+    printf("%s M%lld: %8.1f us  %7.1f TFLOP/s\n", sh.name, (long long)M, us, tf);
+  }
+  return 0;
+}
