@@ -162,7 +162,7 @@ def block_forward(
     a = F.linear(_rb(o, emulate), _rb(g("attn.out_proj.weight"), emulate), g("attn.out_proj.bias"))
     if taps is not None:
         taps["attn_out"] = a
-    x = x + a
+    x = x + _rb(a, emulate)  # the kernels hand the branch to the next LayerNorm kernel as bf16
 
     h = F.layer_norm(x, (D,), g("ln_2.weight"), g("ln_2.bias"), 1e-5)
     h = F.linear(_rb(h, emulate), _rb(g("mlp.c_fc.weight"), emulate), g("mlp.c_fc.bias"))
@@ -170,7 +170,7 @@ def block_forward(
     if taps is not None:
         taps["mlp_hidden"] = h
     h = F.linear(_rb(h, emulate), _rb(g("mlp.c_proj.weight"), emulate), g("mlp.c_proj.bias"))
-    x = x + h
+    x = x + _rb(h, emulate)
     if taps is not None:
         taps["out"] = x
     return x, (p if want_probs else None)

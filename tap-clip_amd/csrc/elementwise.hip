@@ -125,7 +125,9 @@ __global__ void scale_copy_kernel(const float* __restrict__ src, int64_t n, int6
 // (reference models/model_wrapper.py:73-75); encode_text: EOT row, ln_final (clip_wrapper.py:49-51).
 // One workgroup per output row; fp32 FMA throughout (0.8 MFLOP per row).
 template <int NE>  // outputs per thread: E <= 256 * NE
-__global__ __launch_bounds__(256) void pool_project_kernel(const float* __restrict__ src, int tokens, int K,
+__global__ __launch_bounds__(256) void pool_project_kernel(const float* __restrict__ src,
+                                                           const bf16_t* __restrict__ dhi,
+                                                           const bf16_t* __restrict__ dlo, int tokens, int K,
                                                            const int64_t* __restrict__ index, int fixed_token,
                                                            const float* __restrict__ ln_g,
                                                            const float* __restrict__ ln_b,
@@ -139,8 +141,14 @@ __global__ __launch_bounds__(256) void pool_project_kernel(const float* __restri
   int tok = fixed_token;
   if (index != nullptr) tok = (int)index[n];
   if (tok < 0) tok += tokens;
-  const float* xr = src + (n * tokens + tok) * (int64_t)K;
-  for (int c = tid; c < K; c += 256) row[c] = xr[c];
+  const int64_t roff = (n * tokens + tok) * (int64_t)K;
+  const float* xr = src + roff;
+  for (int c = tid; c < K; c += 256) {
+    float t = xr[c];
+    if (dhi != nullptr) t += bf2f(dhi[roff + c]);
+    if (dlo != nullptr) t += bf2f(dlo[roff + c]);
+    row[c] = t;
+  }
   __syncthreads();
   if (ln_g != nullptr) {
     float s = 0.f;
@@ -275,6 +283,15 @@ __global__ __launch_bounds__(256) void logits_kernel(const float* __restrict__ i
   }
 }
 
+__global__ void add_delta_kernel(float* __restrict__ x, const bf16_t* __restrict__ dhi, const bf16_t* __restrict__ dlo,
+                                 int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float t = x[i] + bf2f(dhi[i]);
+  if (dlo != nullptr) t += bf2f(dlo[i]);
+  x[i] = t;
+}
+
 inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
 }  // namespace
@@ -313,18 +330,24 @@ hipError_t launch_scale_copy(const float* src, int64_t n, int64_t scale_n, float
   return hipGetLastError();
 }
 
-hipError_t launch_pool_project(const float* src, int64_t n, int32_t tokens, int32_t K, const int64_t* index,
-                               int32_t fixed_token, const float* ln_g, const float* ln_b, const float* proj,
-                               int32_t E, int32_t normalize, float* out, hipStream_t s) {
+hipError_t launch_pool_project(const float* src, const bf16_t* dhi, const bf16_t* dlo, int64_t n, int32_t tokens,
+                               int32_t K, const int64_t* index, int32_t fixed_token, const float* ln_g,
+                               const float* ln_b, const float* proj, int32_t E, int32_t normalize, float* out,
+                               hipStream_t s) {
   if (E > 1024 || K > 8192 || K % 8 != 0) return hipErrorInvalidValue;
   const dim3 grid((unsigned)n), block(256);
   const size_t sh = (K + 8) * sizeof(float);
   switch ((E + 255) / 256) {
-    case 1: hipLaunchKernelGGL((pool_project_kernel<1>), grid, block, sh, s, src, tokens, K, index, fixed_token, ln_g, ln_b, proj, E, normalize, out); break;
-    case 2: hipLaunchKernelGGL((pool_project_kernel<2>), grid, block, sh, s, src, tokens, K, index, fixed_token, ln_g, ln_b, proj, E, normalize, out); break;
-    case 3: hipLaunchKernelGGL((pool_project_kernel<3>), grid, block, sh, s, src, tokens, K, index, fixed_token, ln_g, ln_b, proj, E, normalize, out); break;
-    default: hipLaunchKernelGGL((pool_project_kernel<4>), grid, block, sh, s, src, tokens, K, index, fixed_token, ln_g, ln_b, proj, E, normalize, out); break;
+    case 1: hipLaunchKernelGGL((pool_project_kernel<1>), grid, block, sh, s, src, dhi, dlo, tokens, K, index, fixed_token, ln_g, ln_b, proj, E, normalize, out); break;
+    case 2: hipLaunchKernelGGL((pool_project_kernel<2>), grid, block, sh, s, src, dhi, dlo, tokens, K, index, fixed_token, ln_g, ln_b, proj, E, normalize, out); break;
+    case 3: hipLaunchKernelGGL((pool_project_kernel<3>), grid, block, sh, s, src, dhi, dlo, tokens, K, index, fixed_token, ln_g, ln_b, proj, E, normalize, out); break;
+    default: hipLaunchKernelGGL((pool_project_kernel<4>), grid, block, sh, s, src, dhi, dlo, tokens, K, index, fixed_token, ln_g, ln_b, proj, E, normalize, out); break;
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_add_delta(float* x, const bf16_t* dhi, const bf16_t* dlo, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(add_delta_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, x, dhi, dlo, n);
   return hipGetLastError();
 }
 

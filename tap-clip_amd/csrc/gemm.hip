@@ -76,11 +76,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   const int KT1 = g.K / BK;
   const int KT = SPLIT ? 3 * KT1 : KT1;
 
+  // accumulators start at the bias: same summation order as gemm256.hip, so a row's result does not
+  // depend on which kernel (i.e. which batch size) computed it
   f32x4_t acc[4][4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < 4; ++j) {
+    f32x4_t bv = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (EPI != EPI_PATCH_F32 && g.bias != nullptr) bv = *reinterpret_cast<const f32x4_t*>(g.bias + n0 + wn * 64 + j * 16 + 4 * q);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i) acc[j][i] = bv;
+  }
 
   // per-thread staging addresses (element offsets into A / W, byte offsets into an LDS tile)
   int64_t a_off[4], w_off[4];
@@ -151,10 +156,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wn * 64 + j * 16 + 4 * q;
       f32x4_t v = acc[j][i];
-      if (EPI != EPI_PATCH_F32 && g.bias != nullptr) {
-        const float4 bv = *reinterpret_cast<const float4*>(g.bias + n);
-        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-      }
       if (EPI == EPI_PATCH_F32) {
         const float4 pv = *reinterpret_cast<const float4*>(addrow + n);
         v[0] += pv.x; v[1] += pv.y; v[2] += pv.z; v[3] += pv.w;
@@ -216,6 +217,7 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 hipError_t launch_gemm256(const GemmArgs& a, int epilogue, bool split, hipStream_t s);  // gemm256.hip
+bool gemm256_supports(const GemmArgs& a);
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, bool split, hipStream_t s) {
   if (a.M <= 0 || a.N % BN != 0 || a.K % BK != 0 || a.K <= 0) return hipErrorInvalidValue;
@@ -227,7 +229,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, bool split, hipStream_t 
     const char* e = getenv("TAPCLIP_GEMM_TILE");
     return e ? atoi(e) : 0;
   }();
-  if (forced == 256 || (forced != 128 && a.M >= 8192)) return launch_gemm256(a, epilogue, split, s);
+  if (gemm256_supports(a) && (forced == 256 || (forced != 128 && a.M >= 8192))) return launch_gemm256(a, epilogue, split, s);
 #define TAPCLIP_GEMM_CASE(E)                                      \
   case E:                                                         \
     return split ? launch_t<E, true>(a, s) : launch_t<E, false>(a, s);

@@ -1,17 +1,33 @@
-// Large-M bf16 MFMA GEMM for gfx950:  C[M,N] = A[M,K] . W[N,K]^T, 256 x BN x 64 tiles (BN = 256 | 128),
-// 512-thread workgroups (8 waves as 2(m) x 4(n)), operands staged global -> LDS by LDS-DMA
-// (global_load_lds_dwordx4: no staging VGPRs, no ds_write), double-buffered.
+// Large-M bf16 MFMA GEMM for gfx950:  C[M,N] = A[M,K] . W[N,K]^T (+ bias, fused epilogues), persistent,
+// 256 x BN output tiles (BN = 256 | 128), 512-thread workgroups (8 waves as 2(m) x 4(n)), operands
+// streamed global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write) through a
+// ring of NS stages of K depth 32.
 //
-// Why 256-wide tiles: a CU's MFMA peak is ~4070 FLOP/clk against ~56 B/clk from L2, so a tile needs
-// >= 73 FLOP per staged byte; 128 x 128 x 64 gives 64, 256 x 128 gives 85, 256 x 256 gives 128.
-// Tile order: XCD-aware (blocks with equal blockIdx % 8 share an L2 and walk a contiguous run of tiles)
-// and grouped (8 m-tiles x all n-tiles per group, m fastest) so the ~64 tiles an XCD has in flight
-// share 8 A panels and 8 W panels out of its 4 MiB L2.
+// Replaces the nn.Linear / conv1 calls of open_clip's image tower (SURVEY.md section 2.1 K1,K3,K5,K6,K7;
+// reference call site models/clip_wrapper.py:47) at M = batch x 197 rows.
 //
-// LDS image of a tile: [rows][64 bf16] = 128-B rows; 16-B chunk p of row r holds source k-chunk
-// p ^ (r & 7).  LDS-DMA writes lane-linearly (lane l -> row l >> 3, chunk l & 7 of an 8-row piece), so
-// the swizzle is applied to each lane's SOURCE address and again on the ds_read_b128 side (guide
-// rule 21).  The MFMA is issued swapped (D = Wfrag . Afrag^T): a lane holds 4 consecutive n of one m.
+// Design notes (all measured on MI355X, profiles/ r01):
+//  * tile size: a CU's MFMA peak is ~4070 FLOP/clk against ~56 B/clk from L2, so a tile needs >= 73
+//    FLOP per staged byte; 128 x 128 gives 64, 256 x 128 gives 85, 256 x 256 gives 128.
+//  * persistent + ring: one workgroup per CU walks its XCD's run of tiles; the K steps of successive
+//    output tiles form ONE linear sequence through the ring, NS - 1 steps are always in flight, and the
+//    waits are hand-counted s_waitcnt vmcnt(N) with raw s_barrier (vmcnt counts loads, stores and LDS-DMA
+//    together, in issue order; __syncthreads() would add vmcnt(0)).  A 2-stage version of this kernel
+//    with __syncthreads() spent ~40 % of a K = 768 launch outside the MFMA loop (prologue latency, store
+//    drain) and stalled on every L2 miss.
+//  * epilogue stores stay in flight across the next tile's first NS - 2 steps: their count (NST) is added
+//    to the wait count there ("relaxed").  That is only valid when the epilogue issues exactly NST
+//    vector-memory ops and no loads, so the bias lives in LDS (loaded once per workgroup) and seeds the
+//    accumulators; epilogues with loads (residual, patch) and ragged / split tiles take vmcnt(0).
+//  * tile order: XCD-aware (blocks with equal blockIdx % 8 share an L2 and own a contiguous chunk of the
+//    tile order) and grouped (8 m-tiles x all n-tiles, m fastest).
+//  * LDS image of a stage: [rows][32 bf16] = 64-B rows; 16-B chunk p of row R holds source k-chunk
+//    p ^ (3 * ((R >> 3) & 1)): with that XOR the four 16-lane groups of a ds_read_b128 fragment read
+//    (rows 0..15 x one k-chunk, middle rows one chunk over) touch 16 distinct 16-B slots.  LDS-DMA writes
+//    lane-linearly (lane l -> row l >> 2, chunk l & 3 of a 16-row piece), so the swizzle is applied to each
+//    lane's SOURCE address and again on the read side (guide rule 21).
+//  * the MFMA is issued swapped (D = Wfrag . Afrag^T): a lane holds 4 consecutive n of one m (8-byte bf16 /
+//    16-byte fp32 stores).
 #include <cstdlib>
 
 #include "common.h"
@@ -22,113 +38,240 @@ namespace {
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 256, BK = 64;
+// LDS accesses of the epilogue transpose go through inline asm: hipcc treats an in-flight LDS-DMA as a
+// pending LDS write and puts s_waitcnt vmcnt(0) in front of any compiler-visible LDS access that may alias
+// it, which would drain the prefetch ring at every epilogue.  The scratch region never aliases the ring.
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)p;
+}
+__device__ __forceinline__ void lds_write_b64(uint32_t addr, unsigned long long v) {
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+// one or two 16-byte reads and the wait for them in ONE statement (guide section 5.7, form (i))
+__device__ __forceinline__ void lds_read_b128_x2(uint32_t a0, uint32_t a1, u32x4_t& v0, u32x4_t& v1) {
+  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v0), "=&v"(v1) : "v"(a0), "v"(a1) : "memory");
+}
+__device__ __forceinline__ void lds_read_b128_x1(uint32_t a0, u32x4_t& v0) {
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v0) : "v"(a0) : "memory");
+}
+
+constexpr int BM = 256, BKS = 32;
 constexpr int GROUP_M = 8;
+constexpr int MAX_N_BIAS = 4096;  // bias vector kept in LDS
 
-template <int EPI, bool SPLIT, int BN>
+template <int EPI, bool SPLIT, int BN, int NS>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
-  constexpr int A_BYTES = BM * BK * 2;
-  constexpr int W_BYTES = BN * BK * 2;
+  constexpr int A_BYTES = BM * BKS * 2;   // 16 KiB
+  constexpr int W_BYTES = BN * BKS * 2;
   constexpr int STAGE = A_BYTES + W_BYTES;
-  constexpr int NJ = BN / 64;  // 16-wide n sub-tiles per wave (wave covers BN / 4 columns)
-  constexpr int WI = BN / 64;  // W pieces (8 rows x 128 B) per wave per stage
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // [2 stages][A | W]
+  constexpr int NJ = BN / 64;             // 16-wide n sub-tiles per wave (wave covers BN / 4 columns)
+  constexpr int AP = 2;                   // A pieces (16 rows x 64 B = 1 KiB) per wave per stage
+  constexpr int WP = BN / 128;            // W pieces per wave per stage
+  constexpr int NDMA = AP + WP;
+  // bf16 outputs of the non-split path leave through a per-wave 2-KiB LDS transpose, 16 rows at a time,
+  // as 16-byte-per-lane stores of whole 128-B (BN = 256) / 64-B (BN = 128) row segments: the natural
+  // fragment store (8 B per lane, 16 rows x 32 B per instruction) was store-ISSUE bound -- 232 MB of
+  // QKV output cost ~100 us of a 236 us launch (gemm_bench NOSTORE experiment, profiles/ r01).
+  constexpr bool TR_EPI = !SPLIT && (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16);
+  constexpr int ROW_CHUNKS = BN / 32;     // 16-B chunks per 16-row scratch row (wave covers BN/4 columns)
+  constexpr int NST = TR_EPI ? 8 * ROW_CHUNKS / 4 : NJ * 8;  // stores per wave of a clean epilogue
+  constexpr int WAIT_STEADY = (NS - 2) * NDMA;
+  constexpr int WAIT_RELAXED = WAIT_STEADY + NST;
+  static_assert(WAIT_RELAXED <= 63, "vmcnt is a 6-bit field");
+  constexpr bool CLEAN_EPI = !SPLIT && (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_BIAS_F32);
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // [NS stages][A | W] then bias[N]
+  float* bias_lds = reinterpret_cast<float*>(smem + NS * STAGE + 8 * 2048);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
   const int wm = wave >> 2, wn = wave & 3;
+  uint8_t* scratch = smem + NS * STAGE + wave * 2048;  // wave-private epilogue transpose buffer
 
-  // ---- block -> tile: XCD-contiguous, then grouped ordering
+  // ---- this workgroup's run of tiles: XCD x (= blockIdx % 8, the blocks that share an L2) owns a
+  // contiguous chunk of the grouped tile order; its gridDim/8 workgroups take ids j, j + bpx, ...
   const int tiles_m = (int)((g.M + BM - 1) / BM);
   const int tiles_n = g.N / BN;
-  const int nwg = gridDim.x;
-  int bid = blockIdx.x;
-  {
-    const int xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
-    bid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-  }
-  const int per_group = GROUP_M * tiles_n;
-  const int grp = bid / per_group;
-  const int first_m = grp * GROUP_M;
-  const int gsize = tiles_m - first_m < GROUP_M ? tiles_m - first_m : GROUP_M;
-  const int in_grp = bid - grp * per_group;
-  const int tm = first_m + in_grp % gsize;
-  const int tn = in_grp / gsize;
-  const int64_t m0 = (int64_t)tm * BM;
-  const int n0 = tn * BN;
+  const int total = tiles_m * tiles_n;
+  const int xcd = blockIdx.x & 7, bpx = gridDim.x >> 3;
+  const int cq = total >> 3, crm = total & 7;
+  const int chunk_lo = xcd * cq + (xcd < crm ? xcd : crm);
+  const int chunk_hi = chunk_lo + cq + (xcd < crm ? 1 : 0);
+  int lid = chunk_lo + (blockIdx.x >> 3);
+  if (lid >= chunk_hi) return;
 
-  const int KT1 = g.K / BK;
-  const int KT = SPLIT ? 3 * KT1 : KT1;
+  // bias -> LDS (zeros when absent); visible after the first barrier below
+  for (int i = tid; i < g.N; i += 512) bias_lds[i] = g.bias ? g.bias[i] : 0.f;
 
-  // ---- LDS-DMA source offsets (elements).  Piece j of a tile = rows 8j .. 8j+7; wave w issues pieces
-  // w, w+8, ...; lane l covers row 8j + (l >> 3), LDS chunk (l & 7) <- source chunk (l & 7) ^ (l >> 3).
-  const int src_chunk = (lane & 7) ^ (lane >> 3);
-  int64_t a_off[4], w_off[WI];
+  const int KS1 = g.K / BKS;
+  const int KS = SPLIT ? 3 * KS1 : KS1;
+
+  // tile id -> (m0, n0): grouped ordering, GROUP_M m-tiles x all n-tiles per group, m fastest
+  auto tile_origin = [&](int id, int64_t& m0, int& n0) {
+    const int per_group = GROUP_M * tiles_n;
+    const int grp = id / per_group;
+    const int first_m = grp * GROUP_M;
+    const int gsize = tiles_m - first_m < GROUP_M ? tiles_m - first_m : GROUP_M;
+    const int in_grp = id - grp * per_group;
+    m0 = (int64_t)(first_m + in_grp % gsize) * BM;
+    n0 = (in_grp / gsize) * BN;
+  };
+  // LDS-DMA source offsets (32-bit BYTE offsets: the launcher checks that A and W are < 4 GiB).
+  // Piece j of a stage = rows 16j .. 16j+15; wave w issues pieces w, w + 8; lane l covers row
+  // 16j + (l >> 2), LDS chunk (l & 3) <- source chunk (l & 3) ^ (3 * ((l >> 5) & 1)).
+  const int src_chunk = (lane & 3) ^ (3 * ((lane >> 5) & 1));
+  auto tile_offsets = [&](int64_t m0, int n0, uint32_t (&a_off)[AP], uint32_t (&w_off)[WP]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int64_t m = m0 + 8 * (wave + 8 * i) + (lane >> 3);
-    if (m >= g.M) m = g.M - 1;  // clamp: rows past M are computed but never stored
-    a_off[i] = m * g.lda + src_chunk * 8;
-  }
-#pragma unroll
-  for (int i = 0; i < WI; ++i) w_off[i] = (int64_t)(n0 + 8 * (wave + 8 * i) + (lane >> 3)) * g.K + src_chunk * 8;
-
-  auto stage = [&](int buf, int kt) {
-    int seg = 0, kk = kt;
-    if (SPLIT) {
-      seg = kt / KT1;
-      kk = kt - seg * KT1;
+    for (int i = 0; i < AP; ++i) {
+      int64_t m = m0 + 16 * (wave + 8 * i) + (lane >> 2);
+      if (m >= g.M) m = g.M - 1;  // clamp: rows past M are computed but never stored
+      a_off[i] = (uint32_t)((m * g.lda + src_chunk * 8) * 2);
     }
-    const bf16_t* Ap = (SPLIT && seg == 1) ? g.A_lo : g.A_hi;
-    const bf16_t* Wp = (SPLIT && seg == 2) ? g.W_lo : g.W_hi;
-    uint8_t* base = smem + buf * STAGE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(Ap + a_off[i] + kk * BK),
-                                       (lds_void_t*)(base + (wave + 8 * i) * 1024), 16, 0, 0);
+    for (int i = 0; i < WP; ++i)
+      w_off[i] = (uint32_t)(((int64_t)(n0 + 16 * (wave + 8 * i) + (lane >> 2)) * g.K + src_chunk * 8) * 2);
+  };
+  auto stage_dma = [&](int st, int ks, const uint32_t (&a_off)[AP], const uint32_t (&w_off)[WP]) {
+    int seg = 0, kk = ks;
+    if (SPLIT) {
+      seg = ks / KS1;
+      kk = ks - seg * KS1;
+    }
+    const uint8_t* Ap = reinterpret_cast<const uint8_t*>((SPLIT && seg == 1) ? g.A_lo : g.A_hi) + kk * (BKS * 2);
+    const uint8_t* Wp = reinterpret_cast<const uint8_t*>((SPLIT && seg == 2) ? g.W_lo : g.W_hi) + kk * (BKS * 2);
+    uint8_t* base = smem + st * STAGE;
 #pragma unroll
-    for (int i = 0; i < WI; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(Wp + w_off[i] + kk * BK),
-                                       (lds_void_t*)(base + A_BYTES + (wave + 8 * i) * 1024), 16, 0, 0);
+    for (int i = 0; i < AP; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(Ap + a_off[i]), (lds_void_t*)(base + (wave + 8 * i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < WP; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(Wp + w_off[i]), (lds_void_t*)(base + A_BYTES + (wave + 8 * i) * 1024), 16, 0, 0);
   };
 
-  f32x4_t acc[NJ][8];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // fragment read offsets within a stage: row R = sub-tile base (multiple of 16) + r
+  const int frag_off = r * 64 + ((q ^ (3 * ((r >> 3) & 1))) << 4);
+  const int a_base = (wm * 128) * 64 + frag_off;
+  const int w_base = A_BYTES + (wn * (BN / 4)) * 64 + frag_off;
 
-  stage(0, 0);
-  __syncthreads();  // emits s_waitcnt vmcnt(0) for the outstanding LDS-DMA, then the barrier
-
-  // fragment read offsets: row & 7 == r & 7 for every sub-tile (their bases are multiples of 16)
-  const int swz = r & 7;
-  const int a_row = (wm * 128 + r) * 128;
-  const int w_row = A_BYTES + (wn * (BN / 4) + r) * 128;
-
-  for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < KT) stage(cur ^ 1, kt + 1);  // the other stage: its readers passed the previous barrier
-    const uint8_t* base = smem + cur * STAGE;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int coff = ((4 * s + q) ^ swz) << 4;
-      bf16x8_t wf[NJ];
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(base + w_row + j * 2048 + coff);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(base + a_row + i * 2048 + coff);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af, acc[j][i], 0, 0, 0);
+  // ---- fetch cursor: the (tile, k-step) whose DMA is issued next; runs NS - 1 steps ahead of compute
+  int f_lid = lid, f_ks = 0;
+  bool f_valid = true;
+  uint32_t a_off[AP], w_off[WP];
+  {
+    int64_t fm0;
+    int fn0;
+    tile_origin(f_lid, fm0, fn0);
+    tile_offsets(fm0, fn0, a_off, w_off);
+  }
+  auto fetch_next = [&](int st) {  // issue the cursor's DMA into stage st, then advance the cursor
+    stage_dma(st, f_ks, a_off, w_off);
+    if (++f_ks == KS) {
+      f_ks = 0;
+      f_lid += bpx;
+      f_valid = f_lid < chunk_hi;
+      if (f_valid) {
+        int64_t fm0;
+        int fn0;
+        tile_origin(f_lid, fm0, fn0);
+        tile_offsets(fm0, fn0, a_off, w_off);
       }
     }
-    __syncthreads();  // vmcnt(0) (next stage landed) + barrier (everyone done reading this stage)
+  };
+
+  // prologue: steps 0 .. NS-2 in flight, then step 0 landed
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i)
+    if (f_valid) fetch_next(i);
+  if (f_valid) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_STEADY) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // ---- staggered halves.  Waves 0-3 (group A, the upper 128 rows) and waves 4-7 (group B, the lower
+  // 128 rows) run the same two-phase step -- READ: epilogue of the finished tile if any, issue the DMA
+  // of step h + NS - 1, load this step's 12 fragments into registers; COMPUTE: 32 (16) MFMAs out of
+  // registers -- but B runs one phase (one barrier) behind A.  A CU places wave w and wave w + 4 on
+  // the same SIMD, so on every SIMD one wave's MFMA phase runs beside the other wave's LDS reads, DMA
+  // issue and epilogue VALU/stores instead of all 8 waves stalling on LDS together after each barrier.
+  // Each wave waits for its OWN DMA pieces of step h + 1 before the barrier that precedes group A's read
+  // of it: group A at the end of its COMPUTE phase, group B at the end of its READ phase.
+  const bool grp_b = wave >= 4;  // wave-uniform (readfirstlane above)
+  if (grp_b) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   }
 
+  int st = 0;        // ring stage of the step being computed
+  int relaxed = 0;   // waits for which the previous epilogue's NST stores may still be in flight
+  bool pending = false;  // a finished tile's accumulators wait for their epilogue
+  int64_t m0 = 0, em0 = 0;
+  int n0 = 0, en0 = 0;
+  f32x4_t acc[NJ][8];
+
+  auto wait_dma = [&](bool issued) {
+    // next step's stage must have landed: all but the youngest (NS-2) stages of DMA -- plus, for the
+    // first NS-2 waits after a clean epilogue, its NST stores -- may stay in flight.  Once the cursor has
+    // run out (the workgroup's last steps) fewer ops are in flight than the counts assume: vmcnt(0).
+    if (!issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (relaxed > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_RELAXED) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_STEADY) : "memory");
+    if (relaxed > 0) --relaxed;
+  };
+
+  auto epilogue = [&](int64_t m0, int n0) {
+    if (g.act == 99) return;  // gemm_bench NOSTORE experiment
+    if (TR_EPI) {
+      // lane (r, q) holds, per 16-row block i and sub-tile j, 4 consecutive n of row 16 i + r.  Write the
+      // block as [16 rows][BN/4 bf16] (16-B chunk c of row rr at slot c ^ (rr & 7): conflict-free both
+      // ways), read it back 16 B per lane in row order, store whole row segments.  Wave-private, and a
+      // wave's LDS instructions execute in order: no barrier, no wait between the write and the read.
+      const int64_t mrow0 = m0 + wm * 128;
+      const int ncol0 = n0 + wn * (BN / 4);
+      const bool full = m0 + BM <= g.M;  // workgroup-uniform
+      const uint32_t sbase = lds_addr(scratch);
+      // read-back positions of this lane: 16-B chunk idx = lane (+ 64) of the [16][ROW_CHUNKS] block
+      uint32_t rd_addr[ROW_CHUNKS / 4 > 0 ? ROW_CHUNKS / 4 : 1];
+      int rd_row[ROW_CHUNKS / 4 > 0 ? ROW_CHUNKS / 4 : 1], rd_col[ROW_CHUNKS / 4 > 0 ? ROW_CHUNKS / 4 : 1];
+#pragma unroll
+      for (int t = 0; t < ROW_CHUNKS / 4; ++t) {
+        const int idx = lane + 64 * t;
+        const int rr = idx / ROW_CHUNKS, c = idx % ROW_CHUNKS;
+        rd_row[t] = rr;
+        rd_col[t] = c * 8;
+        rd_addr[t] = sbase + rr * (ROW_CHUNKS * 16) + ((c ^ (rr & (ROW_CHUNKS - 1))) << 4);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          f32x4_t v = acc[j][i];
+          if (EPI == EPI_BIAS_GELU_BF16) {
+            if (g.act == 0) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = gelu_quick(v[e]);
+            }
+          }
+          const unsigned long long pk = (unsigned long long)pack_bf2(v[0], v[1]) | ((unsigned long long)pack_bf2(v[2], v[3]) << 32);
+          const int chunk = 2 * j + (q >> 1);
+          lds_write_b64(sbase + r * (ROW_CHUNKS * 16) + ((chunk ^ (r & (ROW_CHUNKS - 1))) << 4) + (q & 1) * 8, pk);
+        }
+        u32x4_t val[2];
+        if (ROW_CHUNKS / 4 == 2) lds_read_b128_x2(rd_addr[0], rd_addr[1], val[0], val[1]);
+        else lds_read_b128_x1(rd_addr[0], val[0]);
+#pragma unroll
+        for (int t = 0; t < ROW_CHUNKS / 4; ++t) {
+          const int64_t m = mrow0 + i * 16 + rd_row[t];
+          if (full || m < g.M) *reinterpret_cast<u32x4_t*>(g.out_hi + m * g.ldo + ncol0 + rd_col[t]) = val[t];
+        }
+      }
+      return;
+    }
   // ---- epilogue: lane holds D[n = 4q + e][m = r] of each 16 x 16 tile (e = 0..3)
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -146,10 +289,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
     for (int j = 0; j < NJ; ++j) {
       const int n = n0 + wn * (BN / 4) + j * 16 + 4 * q;
       f32x4_t v = acc[j][i];
-      if (EPI != EPI_PATCH_F32 && g.bias != nullptr) {
-        const float4 bv = *reinterpret_cast<const float4*>(g.bias + n);
-        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-      }
       if (EPI == EPI_PATCH_F32) {
         const float4 pv = *reinterpret_cast<const float4*>(addrow + n);
         v[0] += pv.x; v[1] += pv.y; v[2] += pv.z; v[3] += pv.w;
@@ -190,20 +329,91 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
       }
     }
   }
+  };
+
+  for (;;) {
+    tile_origin(lid, m0, n0);
+    const int next_lid = lid + bpx;
+    const bool has_next = next_lid < chunk_hi;
+
+    for (int ks = 0; ks < KS; ++ks) {
+      // ================= READ phase
+      if (ks == 0) {
+        if (pending) {
+          epilogue(em0, en0);
+          // exactly NST stores were issued and the cursor is still issuing: the next NS-2 waits may skip them
+          relaxed = (CLEAN_EPI && f_valid && (em0 + BM <= g.M)) ? NS - 2 : 0;
+          pending = false;
+        }
+        // accumulators start at the bias (lane holds n = n0 + wn * BN/4 + 16 j + 4 q + e for every m)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(bias_lds + n0 + wn * (BN / 4) + j * 16 + 4 * q);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[j][i] = (EPI == EPI_PATCH_F32) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : bv;
+        }
+      }
+      // stage (st + NS - 1) % NS: its last readers (group B, one phase ago) passed the previous barrier
+      const bool issued = f_valid;
+      if (issued) fetch_next((st + NS - 1) % NS);
+      const uint8_t* base = smem + st * STAGE;
+      bf16x8_t wf[NJ], af[8];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(base + w_base + j * 1024);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(base + a_base + i * 1024);
+      if (grp_b) wait_dma(issued);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers: the stage may be reused
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // ================= COMPUTE phase
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+      if (!grp_b) wait_dma(issued);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      st = (st + 1) % NS;
+    }
+    pending = true;
+    em0 = m0;
+    en0 = n0;
+    if (!has_next) break;
+    lid = next_lid;
+  }
+  // the last tile's epilogue; group A is one phase ahead and owes the barrier group B started with
+  if (!grp_b) {
+    epilogue(em0, en0);
+    __builtin_amdgcn_s_barrier();
+  } else {
+    epilogue(em0, en0);
+  }
 }
 
 template <int EPI, bool SPLIT, int BN>
 hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
+  constexpr int NS = 4;
   static bool attr_set = false;
-  const int smem_bytes = 2 * (BM * BK * 2 + BN * BK * 2);
+  const int smem_bytes = NS * (BM * BKS * 2 + BN * BKS * 2) + 8 * 2048 + MAX_N_BIAS * 4;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI, SPLIT, BN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI, SPLIT, BN, NS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const int64_t nwg = ((a.M + BM - 1) / BM) * (a.N / BN);
-  hipLaunchKernelGGL((gemm256_kernel<EPI, SPLIT, BN>), dim3((unsigned)nwg), dim3(512), smem_bytes, s, a);
+  const int64_t tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
+  // persistent: one workgroup per CU (a multiple of 8 so every XCD gets the same number)
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+    n_cu = prop.multiProcessorCount / 8 * 8;
+    if (n_cu < 8) n_cu = 8;
+  }
+  const int64_t nwg = tiles < n_cu ? (tiles + 7) / 8 * 8 : n_cu;
+  hipLaunchKernelGGL((gemm256_kernel<EPI, SPLIT, BN, NS>), dim3((unsigned)nwg), dim3(512), smem_bytes, s, a);
   return hipGetLastError();
 }
 
@@ -221,6 +431,11 @@ hipError_t launch_e(const GemmArgs& a, bool split, hipStream_t s) {
 }
 
 }  // namespace
+
+bool gemm256_supports(const GemmArgs& a) {
+  return a.N <= MAX_N_BIAS && a.K % BKS == 0 && a.K >= 4 * BKS && (a.M * a.lda * 2 < (int64_t)0xFFFF0000) &&
+         ((int64_t)a.N * a.K * 2 < (int64_t)0xFFFF0000);
+}
 
 hipError_t launch_gemm256(const GemmArgs& a, int epilogue, bool split, hipStream_t s) {
   switch (epilogue) {

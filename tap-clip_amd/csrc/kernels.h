@@ -40,6 +40,13 @@ hipError_t launch_layernorm(const float* x, int64_t ldx, const float* gamma, con
                             int64_t rows, int32_t d, bf16_t* out_hi, bf16_t* out_lo, float* out_f32,
                             hipStream_t s);
 
+// x += delta (bf16 hi [+ lo]) written back in fp32, then LayerNorm(x) -> bf16 hi [+ lo]
+hipError_t launch_add_layernorm(float* x, const bf16_t* delta_hi, const bf16_t* delta_lo, const float* gamma,
+                                const float* beta, int64_t rows, int32_t d, bf16_t* out_hi, bf16_t* out_lo,
+                                hipStream_t s);
+// x[i] += delta_hi[i] (+ delta_lo[i])
+hipError_t launch_add_delta(float* x, const bf16_t* delta_hi, const bf16_t* delta_lo, int64_t n, hipStream_t s);
+
 struct AttnArgs {
   const bf16_t* qkv_hi;  // [n*T, 3D]: q | k | v, head h at columns h*64 .. h*64+63 of each third
   const bf16_t* qkv_lo;
@@ -68,9 +75,11 @@ hipError_t launch_pack(const float* src, int64_t rows, int32_t cols, int64_t src
 hipError_t launch_scale_copy(const float* src, int64_t n, int64_t scale_n, float scale, float* dst, hipStream_t s);
 
 // out[i,:] = normalize?( LN?(src[i, idx_i, :]) @ proj[K, E] )
-hipError_t launch_pool_project(const float* src, int64_t n, int32_t tokens, int32_t K, const int64_t* index,
-                               int32_t fixed_token, const float* ln_g, const float* ln_b, const float* proj,
-                               int32_t E, int32_t normalize, float* out, hipStream_t s);
+// delta_hi/lo (nullable): pending residual branch [n*tokens, K] added to the gathered row first
+hipError_t launch_pool_project(const float* src, const bf16_t* delta_hi, const bf16_t* delta_lo, int64_t n,
+                               int32_t tokens, int32_t K, const int64_t* index, int32_t fixed_token,
+                               const float* ln_g, const float* ln_b, const float* proj, int32_t E,
+                               int32_t normalize, float* out, hipStream_t s);
 
 hipError_t launch_embed_tokens(const float* table, int32_t vocab, const float* pos, const int64_t* tokens,
                                int32_t n, int32_t L, int32_t D, int32_t add_pos, float* out, hipStream_t s);

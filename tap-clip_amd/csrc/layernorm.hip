@@ -9,20 +9,35 @@ namespace tapclip {
 namespace {
 
 // MODE 0: bf16 hi   1: bf16 hi + lo   2: fp32
-template <int MODE, int NV>  // NV float4 per lane: d = 256 * NV
-__global__ __launch_bounds__(256) void ln_vec_kernel(const float* __restrict__ x, int64_t ldx,
+// ADD: the row first receives the pending residual branch, x += delta (bf16 hi [+ lo], the output of the
+// preceding out_proj / c_proj GEMM), and the updated fp32 row is written back before it is normalised.
+template <int MODE, int NV, bool ADD>  // NV float4 per lane: d = 256 * NV
+__global__ __launch_bounds__(256) void ln_vec_kernel(float* __restrict__ x, int64_t ldx,
+                                                     const bf16_t* __restrict__ d_hi, const bf16_t* __restrict__ d_lo,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, int64_t rows, int d,
                                                      bf16_t* out_hi, bf16_t* out_lo, float* out_f32) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const float* xr = x + row * ldx;
+  float* xr = x + row * ldx;
   float4 v[NV];
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    v[j] = *reinterpret_cast<const float4*>(xr + 4 * lane + 256 * j);
+    const int c = 4 * lane + 256 * j;
+    v[j] = *reinterpret_cast<const float4*>(xr + c);
+    if (ADD) {
+      const uint2 h = *reinterpret_cast<const uint2*>(d_hi + row * d + c);
+      v[j].x += bf2f((bf16_t)(h.x & 0xFFFF)); v[j].y += bf2f((bf16_t)(h.x >> 16));
+      v[j].z += bf2f((bf16_t)(h.y & 0xFFFF)); v[j].w += bf2f((bf16_t)(h.y >> 16));
+      if (d_lo != nullptr) {
+        const uint2 l = *reinterpret_cast<const uint2*>(d_lo + row * d + c);
+        v[j].x += bf2f((bf16_t)(l.x & 0xFFFF)); v[j].y += bf2f((bf16_t)(l.x >> 16));
+        v[j].z += bf2f((bf16_t)(l.y & 0xFFFF)); v[j].w += bf2f((bf16_t)(l.y >> 16));
+      }
+      *reinterpret_cast<float4*>(xr + c) = v[j];
+    }
     s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
   }
   const float mean = wave_sum(s) / (float)d;
@@ -64,15 +79,23 @@ __global__ __launch_bounds__(256) void ln_vec_kernel(const float* __restrict__ x
 }
 
 // generic widths (d % 64 == 0, small test models): scalar, two passes over an L1-resident row
-template <int MODE>
-__global__ __launch_bounds__(256) void ln_generic_kernel(const float* __restrict__ x, int64_t ldx,
+template <int MODE, bool ADD>
+__global__ __launch_bounds__(256) void ln_generic_kernel(float* __restrict__ x, int64_t ldx,
+                                                         const bf16_t* __restrict__ d_hi, const bf16_t* __restrict__ d_lo,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, int64_t rows, int d,
                                                          bf16_t* out_hi, bf16_t* out_lo, float* out_f32) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const float* xr = x + row * ldx;
+  float* xr = x + row * ldx;
+  if (ADD) {  // each lane updates (and later re-reads) only its own elements
+    for (int c = lane; c < d; c += 64) {
+      float t = xr[c] + bf2f(d_hi[row * d + c]);
+      if (d_lo != nullptr) t += bf2f(d_lo[row * d + c]);
+      xr[c] = t;
+    }
+  }
   float s = 0.f;
   for (int c = lane; c < d; c += 64) s += xr[c];
   const float mean = wave_sum(s) / (float)d;
@@ -99,19 +122,19 @@ __global__ __launch_bounds__(256) void ln_generic_kernel(const float* __restrict
   }
 }
 
-template <int MODE>
-hipError_t launch_mode(const float* x, int64_t ldx, const float* gamma, const float* beta, int64_t rows,
-                       int32_t d, bf16_t* hi, bf16_t* lo, float* f32, hipStream_t s) {
+template <int MODE, bool ADD>
+hipError_t launch_mode(float* x, int64_t ldx, const bf16_t* dh, const bf16_t* dl, const float* gamma, const float* beta,
+                       int64_t rows, int32_t d, bf16_t* hi, bf16_t* lo, float* f32, hipStream_t s) {
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   if (d % 256 == 0 && d / 256 <= 4 && ldx % 4 == 0) {
     switch (d / 256) {
-      case 1: hipLaunchKernelGGL((ln_vec_kernel<MODE, 1>), grid, block, 0, s, x, ldx, gamma, beta, rows, d, hi, lo, f32); break;
-      case 2: hipLaunchKernelGGL((ln_vec_kernel<MODE, 2>), grid, block, 0, s, x, ldx, gamma, beta, rows, d, hi, lo, f32); break;
-      case 3: hipLaunchKernelGGL((ln_vec_kernel<MODE, 3>), grid, block, 0, s, x, ldx, gamma, beta, rows, d, hi, lo, f32); break;
-      default: hipLaunchKernelGGL((ln_vec_kernel<MODE, 4>), grid, block, 0, s, x, ldx, gamma, beta, rows, d, hi, lo, f32); break;
+      case 1: hipLaunchKernelGGL((ln_vec_kernel<MODE, 1, ADD>), grid, block, 0, s, x, ldx, dh, dl, gamma, beta, rows, d, hi, lo, f32); break;
+      case 2: hipLaunchKernelGGL((ln_vec_kernel<MODE, 2, ADD>), grid, block, 0, s, x, ldx, dh, dl, gamma, beta, rows, d, hi, lo, f32); break;
+      case 3: hipLaunchKernelGGL((ln_vec_kernel<MODE, 3, ADD>), grid, block, 0, s, x, ldx, dh, dl, gamma, beta, rows, d, hi, lo, f32); break;
+      default: hipLaunchKernelGGL((ln_vec_kernel<MODE, 4, ADD>), grid, block, 0, s, x, ldx, dh, dl, gamma, beta, rows, d, hi, lo, f32); break;
     }
   } else {
-    hipLaunchKernelGGL((ln_generic_kernel<MODE>), grid, block, 0, s, x, ldx, gamma, beta, rows, d, hi, lo, f32);
+    hipLaunchKernelGGL((ln_generic_kernel<MODE, ADD>), grid, block, 0, s, x, ldx, dh, dl, gamma, beta, rows, d, hi, lo, f32);
   }
   return hipGetLastError();
 }
@@ -121,9 +144,18 @@ hipError_t launch_mode(const float* x, int64_t ldx, const float* gamma, const fl
 hipError_t launch_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, int64_t rows,
                             int32_t d, bf16_t* out_hi, bf16_t* out_lo, float* out_f32, hipStream_t s) {
   if (rows <= 0 || d <= 0 || d % 64 != 0) return hipErrorInvalidValue;
-  if (out_f32 != nullptr) return launch_mode<2>(x, ldx, gamma, beta, rows, d, nullptr, nullptr, out_f32, s);
-  if (out_lo != nullptr) return launch_mode<1>(x, ldx, gamma, beta, rows, d, out_hi, out_lo, nullptr, s);
-  return launch_mode<0>(x, ldx, gamma, beta, rows, d, out_hi, nullptr, nullptr, s);
+  float* xm = const_cast<float*>(x);  // not written without ADD
+  if (out_f32 != nullptr) return launch_mode<2, false>(xm, ldx, nullptr, nullptr, gamma, beta, rows, d, nullptr, nullptr, out_f32, s);
+  if (out_lo != nullptr) return launch_mode<1, false>(xm, ldx, nullptr, nullptr, gamma, beta, rows, d, out_hi, out_lo, nullptr, s);
+  return launch_mode<0, false>(xm, ldx, nullptr, nullptr, gamma, beta, rows, d, out_hi, nullptr, nullptr, s);
+}
+
+hipError_t launch_add_layernorm(float* x, const bf16_t* delta_hi, const bf16_t* delta_lo, const float* gamma,
+                                const float* beta, int64_t rows, int32_t d, bf16_t* out_hi, bf16_t* out_lo,
+                                hipStream_t s) {
+  if (rows <= 0 || d <= 0 || d % 64 != 0 || delta_hi == nullptr) return hipErrorInvalidValue;
+  if (out_lo != nullptr) return launch_mode<1, true>(x, d, delta_hi, delta_lo, gamma, beta, rows, d, out_hi, out_lo, nullptr, s);
+  return launch_mode<0, true>(x, d, delta_hi, delta_lo, gamma, beta, rows, d, out_hi, nullptr, nullptr, s);
 }
 
 }  // namespace tapclip

@@ -4,13 +4,13 @@
 //
 // Launch sequence of one pre-LN residual block (open_clip ResidualAttentionBlock, reached through
 // reference models/clip_wrapper.py:47 and models/model_wrapper.py:58,72):
-//   LN1 (fp32 x -> bf16)            layernorm.hip
-//   QKV GEMM + bias -> bf16 q|k|v   gemm.hip  EPI_BIAS_BF16      (1/sqrt(hd) folded into Wq, bq)
-//   attention core (+ probs)        attention.hip
-//   out_proj GEMM + bias + residual gemm.hip  EPI_BIAS_RESID_F32 (x updated in place, fp32)
-//   LN2                              layernorm.hip
-//   c_fc GEMM + bias + GELU -> bf16 gemm.hip  EPI_BIAS_GELU_BF16
-//   c_proj GEMM + bias + residual   gemm.hip  EPI_BIAS_RESID_F32
+//   [x += previous c_proj branch] LN1 (fp32 x -> bf16)   layernorm.hip
+//   QKV GEMM + bias -> bf16 q|k|v                       gemm*.hip EPI_BIAS_BF16 (1/sqrt(hd) folded into Wq, bq)
+//   attention core (+ probs)                            attention.hip
+//   out_proj GEMM + bias -> bf16 branch d               gemm*.hip EPI_BIAS_BF16
+//   x += d, LN2                                         layernorm.hip (fused add + norm)
+//   c_fc GEMM + bias + GELU -> bf16                     gemm*.hip EPI_BIAS_GELU_BF16
+//   c_proj GEMM + bias -> bf16 branch d                 gemm*.hip EPI_BIAS_BF16 (added by the next LN1 / the tail)
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -96,6 +96,7 @@ struct Workspace {
   bf16_t *qkv_hi = nullptr, *qkv_lo = nullptr;
   bf16_t *ao_hi = nullptr, *ao_lo = nullptr;
   bf16_t *h_hi = nullptr, *h_lo = nullptr;
+  bf16_t *d_hi = nullptr, *d_lo = nullptr;  // pending residual branch (out_proj / c_proj output)
   float* probs = nullptr;
   size_t bytes = 0;
 };
@@ -121,7 +122,9 @@ Workspace carve(const tapclip_tower* t, int64_t n_seq, int tokens, void* base) {
   w.qkv_hi = static_cast<bf16_t*>(take(M * 3 * D * 2));
   w.ao_hi = static_cast<bf16_t*>(take(M * D * 2));
   w.h_hi = static_cast<bf16_t*>(take(hid_elems * 2));
+  w.d_hi = static_cast<bf16_t*>(take(M * D * 2));
   if (t->split) {
+    w.d_lo = static_cast<bf16_t*>(take(M * D * 2));
     w.xn_lo = static_cast<bf16_t*>(take(M * D * 2));
     w.qkv_lo = static_cast<bf16_t*>(take(M * 3 * D * 2));
     w.ao_lo = static_cast<bf16_t*>(take(M * D * 2));
@@ -218,7 +221,10 @@ int gemm(tapclip_tower* t, int slot, int epi, const bf16_t* a_hi, const bf16_t* 
   return TAPCLIP_OK;
 }
 
-// L residual blocks over x [n_seq*tokens, D] (fp32, updated in place)
+// L residual blocks over x [n_seq*tokens, D] (fp32).  The residual adds are DEFERRED: out_proj and c_proj
+// write their branch as bf16 (hi [+ lo]) into w.d and the next LayerNorm kernel applies x += d before
+// normalising (the fp32 read-modify-write in a GEMM epilogue cost more than the GEMM's MFMA work at
+// N = 768).  On return the last c_proj branch is still pending in w.d: the caller folds it in.
 int run_blocks(tapclip_tower* t, float* x, int64_t n_seq, int tokens, int causal, const Workspace& w,
                float* probs_last, float* attn_out_last, hipStream_t s) {
   const int64_t M = n_seq * tokens;
@@ -228,7 +234,8 @@ int run_blocks(tapclip_tower* t, float* x, int64_t n_seq, int tokens, int causal
     const bool last = li == t->cfg.layers - 1;
     {
       ProfScope ps(t, 1, s);
-      HIP_TRY(launch_layernorm(x, D, L.ln1_g, L.ln1_b, M, D, w.xn_hi, w.xn_lo, nullptr, s));
+      if (li == 0) HIP_TRY(launch_layernorm(x, D, L.ln1_g, L.ln1_b, M, D, w.xn_hi, w.xn_lo, nullptr, s));
+      else HIP_TRY(launch_add_layernorm(x, w.d_hi, w.d_lo, L.ln1_g, L.ln1_b, M, D, w.xn_hi, w.xn_lo, s));
     }
     int rc = gemm(t, 2, EPI_BIAS_BF16, w.xn_hi, w.xn_lo, D, L.wqkv, L.bqkv, M, 3 * D, D, w.qkv_hi, w.qkv_lo, nullptr,
                   3 * D, s);
@@ -243,19 +250,19 @@ int run_blocks(tapclip_tower* t, float* x, int64_t n_seq, int tokens, int causal
       HIP_TRY(launch_attention(a, t->split, s));
     }
     if (last && attn_out_last != nullptr) {
-      // what the reference's hook literally captures: the attention module's output (pre residual)
+      // what the reference's hook literally captures: the attention module's output (pre residual), fp32
       rc = gemm(t, 4, EPI_BIAS_F32, w.ao_hi, w.ao_lo, D, L.wo, L.bo, M, D, D, nullptr, nullptr, attn_out_last, D, s);
       if (rc) return rc;
     }
-    rc = gemm(t, 4, EPI_BIAS_RESID_F32, w.ao_hi, w.ao_lo, D, L.wo, L.bo, M, D, D, nullptr, nullptr, x, D, s);
+    rc = gemm(t, 4, EPI_BIAS_BF16, w.ao_hi, w.ao_lo, D, L.wo, L.bo, M, D, D, w.d_hi, w.d_lo, nullptr, D, s);
     if (rc) return rc;
     {
       ProfScope ps(t, 1, s);
-      HIP_TRY(launch_layernorm(x, D, L.ln2_g, L.ln2_b, M, D, w.xn_hi, w.xn_lo, nullptr, s));
+      HIP_TRY(launch_add_layernorm(x, w.d_hi, w.d_lo, L.ln2_g, L.ln2_b, M, D, w.xn_hi, w.xn_lo, s));
     }
     rc = gemm(t, 5, EPI_BIAS_GELU_BF16, w.xn_hi, w.xn_lo, D, L.wfc, L.bfc, M, F, D, w.h_hi, w.h_lo, nullptr, F, s);
     if (rc) return rc;
-    rc = gemm(t, 6, EPI_BIAS_RESID_F32, w.h_hi, w.h_lo, F, L.wpr, L.bpr, M, D, F, nullptr, nullptr, x, D, s);
+    rc = gemm(t, 6, EPI_BIAS_BF16, w.h_hi, w.h_lo, F, L.wpr, L.bpr, M, D, F, w.d_hi, w.d_lo, nullptr, D, s);
     if (rc) return rc;
   }
   return TAPCLIP_OK;
@@ -457,7 +464,8 @@ int tapclip_encode_image(tapclip_tower_t* t, const float* images, int32_t B, flo
   if (rc) return rc;
   {
     ProfScope ps(t, 7, s);
-    HIP_TRY(launch_pool_project(w.x, B, N, D, nullptr, 0, t->lnpost_g, t->lnpost_b, t->proj, t->cfg.embed_dim, normalize, out, s));
+    // the last c_proj branch is still pending: the pool kernel adds it to the CLS rows it gathers
+    HIP_TRY(launch_pool_project(w.x, w.d_hi, w.d_lo, B, N, D, nullptr, 0, t->lnpost_g, t->lnpost_b, t->proj, t->cfg.embed_dim, normalize, out, s));
   }
   return TAPCLIP_OK;
 }
@@ -479,6 +487,7 @@ int tapclip_text_forward(tapclip_tower_t* t, const float* x_in, int32_t n_seq, i
   float* probs = attn_heads ? attn_heads : (attn_mean ? w.probs : nullptr);
   rc = run_blocks(t, x, n_seq, tokens, causal, w, probs, attn_out, s);
   if (rc) return rc;
+  if (out_hidden) HIP_TRY(launch_add_delta(x, w.d_hi, w.d_lo, (int64_t)n_seq * tokens * D, s));  // last pending branch
   if (attn_mean) HIP_TRY(launch_head_mean(probs, n_seq, t->cfg.heads, tokens, attn_mean, s));
   return TAPCLIP_OK;
 }
@@ -489,7 +498,7 @@ int tapclip_text_pool_project(tapclip_tower_t* t, const float* hidden, int32_t n
   if (t->cfg.kind != TAPCLIP_TOWER_TEXT) return fail(TAPCLIP_EINVAL, "needs a text tower");
   int rc = check_ready(t);
   if (rc) return rc;
-  HIP_TRY(launch_pool_project(hidden, n_seq, tokens, t->cfg.width, index, -1, apply_ln_final ? t->lnfin_g : nullptr,
+  HIP_TRY(launch_pool_project(hidden, nullptr, nullptr, n_seq, tokens, t->cfg.width, index, -1, apply_ln_final ? t->lnfin_g : nullptr,
                               apply_ln_final ? t->lnfin_b : nullptr, t->text_proj, t->cfg.embed_dim, normalize, out,
                               static_cast<hipStream_t>(stream)));
   return TAPCLIP_OK;
