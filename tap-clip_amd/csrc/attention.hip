@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   constexpr int TILE = KEYS * 128;  // bytes of one [KEYS][64] bf16 image
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* Kh = smem;                  // swizzled rows (b128 reads)
-  uint8_t* Vh = smem + TILE;           // plain rows (transposed reads)
+  uint8_t* Vh = smem + TILE;           // rows with swizzled 32-B blocks (transposed reads)
   uint8_t* Kl = smem + 2 * TILE;       // SPLIT only
   uint8_t* Vl = smem + 3 * TILE;
 
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
       const int c = tid + 256 * it;
       const int key = c >> 3, kc = c & 7;
       const int ko = key * 128 + ((kc ^ (key & 7)) << 4);
-      const int vo = key * 128 + (kc << 4);
+      const int vo = key * 128 + (((((kc >> 1) ^ (key >> 1)) & 3) << 1 | (kc & 1)) << 4);  // 32-B block ^ ((key>>1)&3): conflict-free tr reads
       *reinterpret_cast<uint4*>(Kh + ko) = kv[it];
       *reinterpret_cast<uint4*>(Vh + vo) = vv[it];
       if (SPLIT) {
@@ -204,9 +204,10 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
       }
       const int key0 = 16 * (2 * s2) + 4 * g + qq;
       const int key1 = 16 * (2 * s2 + 1) + 4 * g + qq;
+      const int sw = (key0 >> 1) & 3;  // == (key1 >> 1) & 3: the keys differ by 16
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const int coff = (16 * dt + 4 * pp) * 2;
+        const int coff = ((dt ^ sw) << 5) + 8 * pp;  // swizzled 32-B block of the 16 d's, 8 B per lane
         const bf16x8_t vf = tr_pair(Vh + key0 * 128 + coff, Vh + key1 * 128 + coff);
         oc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, ph, oc[dt], 0, 0, 0);
         if (SPLIT) {

@@ -162,8 +162,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
       }
       if (EPI == EPI_BIAS_GELU_BF16) {
         if (g.act == 0) {
+          // bf16 path: the fitted form (2.5e-5 abs, common.h), same as gemm256.hip so that a row's result
+          // does not depend on the kernel / batch size; bf16x3 keeps the 5e-7 erf
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+          for (int e = 0; e < 4; ++e) v[e] = SPLIT ? gelu_erf(v[e]) : gelu_erf_fast(v[e]);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = gelu_quick(v[e]);

@@ -28,6 +28,7 @@
 //    lane's SOURCE address and again on the read side (guide rule 21).
 //  * the MFMA is issued swapped (D = Wfrag . Afrag^T): a lane holds 4 consecutive n of one m (8-byte bf16 /
 //    16-byte fp32 stores).
+#include <cmath>
 #include <cstdlib>
 
 #include "common.h"
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
           if (EPI == EPI_BIAS_GELU_BF16) {
             if (g.act == 0) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+              for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);  // bf16 path: 2.5e-5 abs, see common.h
             } else {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = gelu_quick(v[e]);
@@ -425,7 +426,14 @@ hipError_t launch_e(const GemmArgs& a, bool split, hipStream_t s) {
     const char* e = getenv("TAPCLIP_GEMM_BN");  // tests: pin the n-tile width
     return e ? atoi(e) : 0;
   }();
-  const bool wide = (a.N % 256 == 0) && (forced_bn == 256 || (forced_bn != 128 && tiles_m * (a.N / 256) >= 6 * 256));
+  // 256-wide tiles have 1.5x the FLOP per staged byte (the main loop is L2->LDS bound) but half as many
+  // tiles: take them unless their last, partial round of 256 workgroups wastes more than that gains
+  bool wide = false;
+  if (a.N % 256 == 0) {
+    const double r256 = (double)(tiles_m * (a.N / 256)) / 256.0, r128 = (double)(tiles_m * (a.N / 128)) / 256.0;
+    const double t256 = std::ceil(r256) * 1.0, t128 = std::ceil(r128) * 0.5 * 1.25;  // relative time per round
+    wide = forced_bn == 256 || (forced_bn != 128 && t256 <= t128);
+  }
   if (wide) return split ? launch_t<EPI, true, 256>(a, s) : launch_t<EPI, false, 256>(a, s);
   return split ? launch_t<EPI, true, 128>(a, s) : launch_t<EPI, false, 128>(a, s);
 }
