@@ -75,13 +75,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    dev = torch.device("cuda", local_rank)
+    # (TAPCLIP_DIST_BACKEND=gloo rehearses N > 1 on a box with fewer GPUs than ranks: ranks share devices)
+    backend = os.environ.get("TAPCLIP_DIST_BACKEND", "nccl")
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import tap_clip_amd
     from tap_clip_amd import configs, engine, synth
@@ -128,7 +133,7 @@ def main():
     prof = vision.profile_read() if events else None
     vision.profile(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert out.shape == (args.batch * world, args.classes) and bool(torch.isfinite(out).all())

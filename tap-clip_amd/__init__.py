@@ -7,6 +7,19 @@ from . import configs, synth  # noqa: F401  (pure host-side helpers, importable 
 __all__ = ["configs", "synth", "engine", "models", "dist"]
 
 
+def install_as_models() -> None:
+    """Make the reference's own import lines resolve to this package:
+    `from models.clip_wrapper import CLIPWrapper`, `from models.model_wrapper import FullModel`
+    (reference train.py:3-4, test_cross_domain.py:4-5) then need no edit at all."""
+    import importlib
+    import sys
+
+    pkg = importlib.import_module(f"{__name__}.models")
+    sys.modules["models"] = pkg
+    for sub in ("clip_wrapper", "model_wrapper", "prompt_learner", "attribution_monitor", "prompt_adjustor"):
+        sys.modules[f"models.{sub}"] = importlib.import_module(f"{__name__}.models.{sub}")
+
+
 def __getattr__(name):
     if name in ("engine", "models", "dist", "_lib"):
         import importlib

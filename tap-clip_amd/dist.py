@@ -17,8 +17,13 @@ def all_gather_rows(x: torch.Tensor, group=None) -> torch.Tensor:
         return x
     x = x.contiguous()
     world = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo":
+        # CPU rehearsal backend (tests; several ranks sharing one GPU): stage through host memory
+        parts = [torch.empty(x.shape, dtype=x.dtype) for _ in range(world)]
+        dist.all_gather(parts, x.detach().cpu(), group=group)
+        return torch.cat(parts, dim=0).to(x.device)
     out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-    dist.all_gather_into_tensor(out, x, group=group)
+    dist.all_gather_into_tensor(out, x, group=group)  # RCCL over xGMI
     return out
 
 

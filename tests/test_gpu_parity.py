@@ -328,3 +328,44 @@ def test_errors(eng):
         eng.VisionTower(cfg, bad, DEV, "bf16")
     with pytest.raises(RuntimeError, match="no CPU path"):
         eng.VisionTower(cfg, sd, "cpu", "bf16")
+
+
+# ---- N > 1: two ranks (sharing the one GPU of the test box, gloo transport) ----------------------
+_RANK_SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import tap_clip_amd
+from tap_clip_amd import configs, synth
+from tap_clip_amd.dist import shard_rows
+from tap_clip_amd.models import CLIPWrapper, FullModel
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+cfg = configs.get_config("tiny")
+sd = synth.make_state_dict(cfg, seed=2)
+names = ["Backpack", "Laptop", "Mug"]
+def build(gather):
+    torch.manual_seed(7)   # same context draw on every rank
+    clip = CLIPWrapper("tiny", None, "cuda:0", precision="bf16x3", state_dict=sd)
+    return FullModel(names, clip, prompt_len=5, class_specific=True, gather_images=gather).eval()
+images = synth.make_images(8, cfg, 0)
+lo, hi = shard_rows(8, rank, world)
+with torch.no_grad():
+    sharded = build(True)(images[lo:hi].cuda())["logits"].cpu()      # every rank: GLOBAL logits
+    full = build(False)(images.cuda())["logits"].cpu()               # single-process answer
+assert sharded.shape == (8, 3), sharded.shape
+err = float((sharded - full).abs().max() / full.abs().max())
+assert err < 1e-5, err
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok", err)
+"""
+
+
+def test_two_ranks_sharded_forward_equals_single(tmp_path):
+    import os, subprocess, sys
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    port = 29600 + os.getpid() % 300
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.count("ok") == 2, r.stdout[-2000:] + r.stderr[-2000:]
