@@ -6,7 +6,7 @@
 // that the reference's forward hook is documented to capture (reference models/clip_wrapper.py:29-40;
 // K4').  1/sqrt(64) is folded into Wq/bq at weight-pack time.
 //
-// One 256-thread workgroup per (sequence, head); the head's whole K and V (<= 256 x 64 bf16) sit in
+// One 512-thread workgroup (8 waves; two of them fit a CU's LDS, i.e. 4 waves per SIMD) per (sequence, head); the head's whole K and V (<= 256 x 64 bf16) sit in
 // LDS; each wave owns 16-query tiles.  All products are issued "transposed" so softmax is lane-local:
 //   S^T[key, q] = K . Q^T   (A = K rows from LDS by ds_read_b128, B = Q rows straight from global)
 //     -> lane (r = lane & 15, g = lane >> 4) holds, for query r, keys 16*kt + 4*g + e (e = 0..3) of
@@ -33,7 +33,7 @@ __device__ __forceinline__ bf16x8_t tr_pair(const uint8_t* base0, const uint8_t*
 }
 
 template <int NKT, bool SPLIT>
-__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+__global__ __launch_bounds__(512) void attn_kernel(AttnArgs a) {
   constexpr int KEYS = NKT * 16;
   constexpr int TILE = KEYS * 128;  // bytes of one [KEYS][64] bf16 image
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -53,12 +53,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 
   // ---- Q fragments of every q-tile this wave owns, issued BEFORE the K/V staging so their latency
   // overlaps it.  B[k = d = 32*s + 8*g + j][col = q]; queries past T are clamped (never stored).
-  constexpr int QT_MAX = (NKT + 3) / 4;
+  constexpr int QT_MAX = (NKT + 7) / 8;  // 16-query tiles per wave (8 waves)
   const int n_qt = (T + 15) >> 4;
   bf16x8_t qh[QT_MAX][2], ql[SPLIT ? QT_MAX : 1][2];
 #pragma unroll
   for (int t = 0; t < QT_MAX; ++t) {
-    int qc = (wave + 4 * t) * 16 + r;
+    int qc = (wave + 8 * t) * 16 + r;
     if (qc >= T) qc = T - 1;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -70,12 +70,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 
   // ---- stage K (swizzled) and V (plain) of this head into LDS; rows >= T are zero.  The trip count
   // is a compile-time constant so all the global loads are in flight together.
-  constexpr int N_IT = KEYS * 8 / 256;
+  constexpr int N_IT = (KEYS * 8 + 511) / 512;
   {
     uint4 kv[N_IT], vv[N_IT], kvl[SPLIT ? N_IT : 1], vvl[SPLIT ? N_IT : 1];
 #pragma unroll
     for (int it = 0; it < N_IT; ++it) {
-      const int c = tid + 256 * it;
+      const int c = tid + 512 * it;
       const int key = c >> 3, kc = c & 7;
       kv[it] = make_uint4(0, 0, 0, 0);
       vv[it] = kv[it];
@@ -95,8 +95,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     }
 #pragma unroll
     for (int it = 0; it < N_IT; ++it) {
-      const int c = tid + 256 * it;
+      const int c = tid + 512 * it;
       const int key = c >> 3, kc = c & 7;
+      if (key >= KEYS) continue;  // KEYS * 8 need not be a multiple of 512
       const int ko = key * 128 + ((kc ^ (key & 7)) << 4);
       const int vo = key * 128 + (((((kc >> 1) ^ (key >> 1)) & 3) << 1 | (kc & 1)) << 4);  // 32-B block ^ ((key>>1)&3): conflict-free tr reads
       *reinterpret_cast<uint4*>(Kh + ko) = kv[it];
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 
 #pragma unroll
   for (int t = 0; t < QT_MAX; ++t) {
-    const int qt = wave + 4 * t;
+    const int qt = wave + 8 * t;
     if (qt >= n_qt) break;       // wave-uniform
     const int qi = qt * 16 + r;  // this lane's query (column of S^T)
 
@@ -254,7 +255,7 @@ hipError_t launch_t(const AttnArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((attn_kernel<NKT, SPLIT>), dim3((unsigned)(a.n_seq * a.H)), dim3(256), smem_bytes, s, a);
+  hipLaunchKernelGGL((attn_kernel<NKT, SPLIT>), dim3((unsigned)(a.n_seq * a.H)), dim3(512), smem_bytes, s, a);
   return hipGetLastError();
 }
 

@@ -269,18 +269,26 @@ __global__ void build_prompts_kernel(const float* __restrict__ ctx, const float*
 }
 
 // ---- K13: logits[b, c] = scale * <img[b], txt[c]> (reference models/model_wrapper.py:79,83).
-// One workgroup per image row; each wave walks classes, lanes split E.
+// One thread per logit, float4 loads (both operands are a few hundred KB: L1/L2 resident).
 __global__ __launch_bounds__(256) void logits_kernel(const float* __restrict__ img, const float* __restrict__ txt,
-                                                     float scale, int C, int E, float* out) {
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                                     float scale, int B, int C, int E, float* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * C) return;
+  const int b = (int)(i / C), c = (int)(i - (int64_t)b * C);
   const float* ir = img + (int64_t)b * E;
-  for (int c = wave; c < C; c += 4) {
-    const float* tr = txt + (int64_t)c * E;
-    float s = 0.f;
-    for (int e = lane; e < E; e += 64) s = fmaf(ir[e], tr[e], s);
-    s = wave_sum(s);
-    if (lane == 0) out[(int64_t)b * C + c] = scale * s;
+  const float* tr = txt + (int64_t)c * E;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int e = 0;
+  if (E % 4 == 0) {
+#pragma unroll 4
+    for (; e < E; e += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(ir + e);
+      const float4 w = *reinterpret_cast<const float4*>(tr + e);
+      s0 = fmaf(a.x, w.x, s0); s1 = fmaf(a.y, w.y, s1); s2 = fmaf(a.z, w.z, s2); s3 = fmaf(a.w, w.w, s3);
+    }
   }
+  for (; e < E; ++e) s0 = fmaf(ir[e], tr[e], s0);
+  out[i] = scale * ((s0 + s1) + (s2 + s3));
 }
 
 __global__ void add_delta_kernel(float* __restrict__ x, const bf16_t* __restrict__ dhi, const bf16_t* __restrict__ dlo,
@@ -373,7 +381,7 @@ hipError_t launch_build_prompts(const float* ctx, const float* tok, const float*
 
 hipError_t launch_logits(const float* img, const float* txt, float scale, int32_t B, int32_t C, int32_t E, float* out,
                          hipStream_t s) {
-  hipLaunchKernelGGL(logits_kernel, dim3((unsigned)B), dim3(256), 0, s, img, txt, scale, C, E, out);
+  hipLaunchKernelGGL(logits_kernel, dim3(blocks_for((int64_t)B * C, 256)), dim3(256), 0, s, img, txt, scale, B, C, E, out);
   return hipGetLastError();
 }
 
