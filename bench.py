@@ -172,10 +172,20 @@ def main():
                 g_n += n
             kern[k] = e
         achieved = g_fl / (g_ms * 1e-3) / 1e12
+        # L2-fabric-side bytes per launch of the same kernel family from the committed PMC passes (separate
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this script, tools/pmc_traffic.py); None if absent
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic_bench.json")
+        if os.path.exists(tpath) and args.batch == 256 and args.model == "ViT-B-16":
+            try:
+                traffic = json.load(open(tpath)).get("gemm_family_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
         result["roofline"] = {
             "kernel": "gemm_kernel<EPI,false> (bf16 MFMA 16x16x32, 128x128x64 tile): QKV + out_proj + c_fc/GELU + c_proj launches",
             "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            "traffic_note": "bytes/launch at the L2 fabric side (FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits included) from profiles/r01_pmc_traffic_bench.json; algorithmic operand+output bytes per launch average 301 MB",
             "flops_per_launch": round(g_fl / g_n), "avg_launch_us": round(1e3 * g_ms / g_n, 2), "launches_per_step": g_n / args.steps,
         }
         ln = prof.get("layernorm")
