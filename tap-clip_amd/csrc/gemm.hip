@@ -224,14 +224,15 @@ bool gemm256_supports(const GemmArgs& a);
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, bool split, hipStream_t s) {
   if (a.M <= 0 || a.N % BN != 0 || a.K % BK != 0 || a.K <= 0) return hipErrorInvalidValue;
   if ((a.lda % 8) != 0 || (a.ldo % 4) != 0) return hipErrorInvalidValue;
-  // large problems (the image tower: M = 50 432): 256-row tiles staged by LDS-DMA; small ones (the text
-  // tower: M = 6 045) keep 128 x 128 tiles so the grid still covers the 256 CUs
+  // M >= 2048 (the image tower: M = 50 432; the 65-class text pass: M = 6 045): the persistent 256-row kernel
+  // of gemm256.hip.  The register-staged kernel in this file is latency-bound at K = 512 (57 us per text
+  // GEMM against ~15 us) and keeps only the small problems: few classes, unit tests, tiny models.
   // TAPCLIP_GEMM_TILE=128|256 pins the choice (tests exercise both kernels on the same problem)
   static const int forced = [] {
     const char* e = getenv("TAPCLIP_GEMM_TILE");
     return e ? atoi(e) : 0;
   }();
-  if (gemm256_supports(a) && (forced == 256 || (forced != 128 && a.M >= 8192))) return launch_gemm256(a, epilogue, split, s);
+  if (gemm256_supports(a) && (forced == 256 || (forced != 128 && a.M >= 2048))) return launch_gemm256(a, epilogue, split, s);
 #define TAPCLIP_GEMM_CASE(E)                                      \
   case E:                                                         \
     return split ? launch_t<E, true>(a, s) : launch_t<E, false>(a, s);
