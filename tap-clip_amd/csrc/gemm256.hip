@@ -54,6 +54,19 @@ __device__ __forceinline__ void lds_write_b64(uint32_t addr, unsigned long long 
 __device__ __forceinline__ void lds_read_b128_x2(uint32_t a0, uint32_t a1, u32x4_t& v0, u32x4_t& v1) {
   asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v0), "=&v"(v1) : "v"(a0), "v"(a1) : "memory");
 }
+// un-waited 16-byte read (guide section 5.7 form (ii)): the destination is only valid after one of the
+// lds_wait_* statements below, which name it "+v" so that no consumer can be scheduled above the wait
+__device__ __forceinline__ void lds_read_b128_nowait(uint32_t a0, u32x4_t& v0) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v0) : "v"(a0) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait_x2(u32x4_t& v0, u32x4_t& v1) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(v0), "+v"(v1) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait_x1(u32x4_t& v0) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v0) : "n"(N) : "memory");
+}
 __device__ __forceinline__ void lds_read_b128_x1(uint32_t a0, u32x4_t& v0) {
   asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v0) : "v"(a0) : "memory");
 }
@@ -75,7 +88,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
   // as 16-byte-per-lane stores of whole 128-B (BN = 256) / 64-B (BN = 128) row segments: the natural
   // fragment store (8 B per lane, 16 rows x 32 B per instruction) was store-ISSUE bound -- 232 MB of
   // QKV output cost ~100 us of a 236 us launch (gemm_bench NOSTORE experiment, profiles/ r01).
-  constexpr bool TR_EPI = !SPLIT && (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16);
+  // (the GELU epilogue keeps the direct 8-byte fragment stores: its VALU work between them hides the store
+  // issue cost, and the extra LDS round trip only adds to an already VALU-bound epilogue: 284 vs 314 us)
+  constexpr bool TR_EPI = !SPLIT && EPI == EPI_BIAS_BF16;
   constexpr int ROW_CHUNKS = BN / 32;     // 16-B chunks per 16-row scratch row (wave covers BN/4 columns)
   constexpr int NST = TR_EPI ? 8 * ROW_CHUNKS / 4 : NJ * 8;  // stores per wave of a clean epilogue
   constexpr int WAIT_STEADY = (NS - 2) * NDMA;
@@ -244,6 +259,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
         rd_col[t] = c * 8;
         rd_addr[t] = sbase + rr * (ROW_CHUNKS * 16) + ((c ^ (rr & (ROW_CHUNKS - 1))) << 4);
       }
+      // software pipeline over the 8 row blocks: a wave's LDS instructions execute in order, so block
+      // i + 1 may be written right behind the (un-waited) reads of block i; the reads of block i are
+      // waited for with a COUNTED lgkmcnt (NJ writes + R reads of block i + 1 stay in flight) just before
+      // its global stores, and block i + 1's GELU/pack VALU work runs under block i's LDS latency.
+      constexpr int R = ROW_CHUNKS / 4;  // 16-B reads (= global stores) per lane per block
+      u32x4_t val[2][2];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -262,14 +283,24 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
           const int chunk = 2 * j + (q >> 1);
           lds_write_b64(sbase + r * (ROW_CHUNKS * 16) + ((chunk ^ (r & (ROW_CHUNKS - 1))) << 4) + (q & 1) * 8, pk);
         }
-        u32x4_t val[2];
-        if (ROW_CHUNKS / 4 == 2) lds_read_b128_x2(rd_addr[0], rd_addr[1], val[0], val[1]);
-        else lds_read_b128_x1(rd_addr[0], val[0]);
 #pragma unroll
-        for (int t = 0; t < ROW_CHUNKS / 4; ++t) {
-          const int64_t m = mrow0 + i * 16 + rd_row[t];
-          if (full || m < g.M) *reinterpret_cast<u32x4_t*>(g.out_hi + m * g.ldo + ncol0 + rd_col[t]) = val[t];
+        for (int t = 0; t < R; ++t) lds_read_b128_nowait(rd_addr[t], val[i & 1][t]);
+        if (i > 0) {  // block i - 1: everything but this block's NJ writes + R reads has completed
+          if (R == 2) lds_wait_x2<NJ + R>(val[(i - 1) & 1][0], val[(i - 1) & 1][1]);
+          else lds_wait_x1<NJ + R>(val[(i - 1) & 1][0]);
+#pragma unroll
+          for (int t = 0; t < R; ++t) {
+            const int64_t m = mrow0 + (i - 1) * 16 + rd_row[t];
+            if (full || m < g.M) *reinterpret_cast<u32x4_t*>(g.out_hi + m * g.ldo + ncol0 + rd_col[t]) = val[(i - 1) & 1][t];
+          }
         }
+      }
+      if (R == 2) lds_wait_x2<0>(val[1][0], val[1][1]);
+      else lds_wait_x1<0>(val[1][0]);
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+        const int64_t m = mrow0 + 7 * 16 + rd_row[t];
+        if (full || m < g.M) *reinterpret_cast<u32x4_t*>(g.out_hi + m * g.ldo + ncol0 + rd_col[t]) = val[1][t];
       }
       return;
     }
@@ -297,7 +328,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
       if (EPI == EPI_BIAS_GELU_BF16) {
         if (g.act == 0) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+          for (int e = 0; e < 4; ++e) v[e] = SPLIT ? gelu_erf(v[e]) : gelu_erf_fast(v[e]);  // see common.h
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = gelu_quick(v[e]);
