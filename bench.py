@@ -212,6 +212,29 @@ def main():
                                                   "attention-map write-back on, batch %d" % args.batch,
                                       "ms_per_forward": round(1e3 * dt, 3), "logits_per_sec": round(args.batch * args.classes / dt, 1),
                                       "images_per_sec": round(args.batch / dt, 1)}
+        # prompt-tuning step (reference train.py:99-105): forward + loss + backward to context_bank + AdamW
+        labels = synth.make_labels(args.batch, args.classes).to(dev)
+        opt = torch.optim.AdamW(model.prompt_learner.parameters(), lr=2e-3, weight_decay=0.01)
+        model.train()
+
+        def train_step():
+            out_t = model(images, labels)
+            opt.zero_grad(set_to_none=True)
+            out_t["loss"].backward()
+            opt.step()
+
+        for _ in range(2):
+            train_step()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(n_it):
+            train_step()
+        torch.cuda.synchronize(dev)
+        dt_t = (time.perf_counter() - t1) / n_it
+        model.eval()
+        result["train_step"] = {"workload": "prompt-tuning step: FullModel forward + CE + backward to 65 x [16,512] context tokens + AdamW, "
+                                            "batch %d (image tower forward only: frozen)" % args.batch,
+                                "ms_per_step": round(1e3 * dt_t, 3), "images_per_sec": round(args.batch / dt_t, 1)}
     if world > 1:
         dist.barrier()
 

@@ -120,6 +120,27 @@ int tapclip_text_pool_project(tapclip_tower_t* text, const float* hidden, int32_
                               int32_t tokens, const int64_t* index, int32_t apply_ln_final,
                               int32_t normalize, float* out, tapclip_stream_t stream);
 
+/* ---- prompt-tuning backward (reference train.py:99-105: `loss.backward()`; only
+ * `prompt_learner.context_bank.*` and `logit_scale` receive gradients, every CLIP weight is frozen,
+ * clip_wrapper.py:19-20, so these are dX-only).  Stateless: tapclip_text_backward recomputes the forward
+ * from x (the tensor given to tapclip_text_forward) inside its own workspace.
+ *   grad_hidden [n,T,D] = dL/d(out_hidden)  ->  grad_x [n,T,D] = dL/dx   (may alias grad_hidden) */
+size_t tapclip_text_backward_workspace_bytes(const tapclip_tower_t* text, int64_t n_seq, int32_t tokens);
+int tapclip_text_backward(tapclip_tower_t* text, const float* x, const float* grad_hidden, int32_t n_seq,
+                          int32_t tokens, int32_t causal, float* grad_x, void* workspace,
+                          size_t workspace_bytes, tapclip_stream_t stream);
+/* backward of tapclip_text_pool_project with index == NULL (token T-1), no ln_final (model_wrapper.py:73-75):
+ * grad_out [n,E] -> grad_hidden [n,T,D] (zero except row T-1). */
+int tapclip_text_pool_project_backward(tapclip_tower_t* text, const float* hidden, int32_t n_seq,
+                                       int32_t tokens, int32_t normalize, const float* grad_out,
+                                       float* grad_hidden, tapclip_stream_t stream);
+/* backward of tapclip_logits w.r.t. txt and log(scale) (model_wrapper.py:26,79; img carries no gradient):
+ * grad_txt[c,e] = scale * sum_b grad_logits[b,c] img[b,e];  *grad_log_scale = sum grad_logits * logits
+ * (grad_log_scale nullable). */
+int tapclip_logits_backward(const float* grad_logits, const float* logits, const float* img, float scale,
+                            int32_t B, int32_t C, int32_t E, float* grad_txt, float* grad_log_scale,
+                            tapclip_stream_t stream);
+
 /* ---- token_embedding(tokens) + positional_embedding (open_clip encode_text prologue;
  * reference models/prompt_learner.py:32-33 calls token_embedding alone: add_pos = 0).
  * tokens [n,L] int64 -> out [n,L,D] fp32. */

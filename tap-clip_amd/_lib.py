@@ -30,6 +30,10 @@ SYMBOLS = [
     ("tapclip_encode_image", _i32, [_p, _p, _i32, _p, _i32, _p, _sz, _p]),
     ("tapclip_text_forward", _i32, [_p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     ("tapclip_text_pool_project", _i32, [_p, _p, _i32, _i32, _p, _i32, _i32, _p, _p]),
+    ("tapclip_text_backward_workspace_bytes", _sz, [_p, _i64, _i32]),
+    ("tapclip_text_backward", _i32, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _sz, _p]),
+    ("tapclip_text_pool_project_backward", _i32, [_p, _p, _i32, _i32, _i32, _p, _p, _p]),
+    ("tapclip_logits_backward", _i32, [_p, _p, _p, _f32, _i32, _i32, _i32, _p, _p, _p]),
     ("tapclip_embed_tokens", _i32, [_p, _p, _i32, _i32, _i32, _p, _p]),
     ("tapclip_attribution", _i32, [_p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     ("tapclip_build_prompts", _i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p]),

@@ -1,0 +1,309 @@
+// Backward kernels of the prompt-tuning step (reference train.py:99-105: loss.backward() reaches only
+// `prompt_learner.context_bank.*` and `logit_scale`; every CLIP weight is frozen, clip_wrapper.py:19-20).
+// The gradient therefore flows  logits -> text features -> token -1 of the text transformer ->
+// activations only (dX, never dW) -> the scaled context tokens.  The image tower needs no backward.
+//
+// GEMM dgrads re-use gemm*.hip with transposed packed weights; this file holds what is not a GEMM:
+//   attn_bwd_kernel      softmax-attention backward per (sequence, head), fp32 VALU out of LDS
+//                        (the text tower is 65 x 93 tokens: ~35 GFLOP per step, latency- not MFMA-bound)
+//   ln_bwd_kernel        LayerNorm backward, fused with the residual-gradient accumulation
+//   pool_project_bwd     d(token pick -> @ text_projection -> L2 norm)   (model_wrapper.py:73-75)
+//   logits_bwd           d(scale * img . txt^T) w.r.t. txt and log-scale  (model_wrapper.py:79)
+//   pack_transpose       W[N,K] fp32 -> W^T[K,N] bf16 hi (+ lo)
+#include "common.h"
+#include "kernels.h"
+
+namespace tapclip {
+namespace {
+
+__device__ __forceinline__ float ld_bf(const bf16_t* hi, const bf16_t* lo, int64_t i) {
+  float v = bf2f(hi[i]);
+  if (lo != nullptr) v += bf2f(lo[i]);
+  return v;
+}
+__device__ __forceinline__ void st_bf(bf16_t* hi, bf16_t* lo, int64_t i, float v) {
+  if (lo != nullptr) {
+    bf16_t h, l;
+    split_bf(v, h, l);
+    hi[i] = h;
+    lo[i] = l;
+  } else {
+    hi[i] = f2bf(v);
+  }
+}
+
+// ---- attention backward.  One 256-thread workgroup per (sequence, head); T <= 128.
+// LDS: q, k, v, dO as fp32 [T][65] (65: conflict-free row and column walks) + P/dS [T][T+1] + delta[T].
+//   S = q k^T (q carries the folded 1/sqrt(64)),  P = softmax(S),  dV = P^T dO,
+//   dP = dO v^T,  delta_i = sum_d dO_id O_id,  dS = P (dP - delta),  dq = dS k,  dk = dS^T q.
+constexpr int BWD_LD = 65;
+
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
+  extern __shared__ float sh[];
+  const int T = a.T, D = a.D;
+  float* q = sh;
+  float* k = q + T * BWD_LD;
+  float* v = k + T * BWD_LD;
+  float* dO = v + T * BWD_LD;
+  float* P = dO + T * BWD_LD;  // [T][T+1]
+  float* delta = P + T * (T + 1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int seq = blockIdx.x / a.H, head = blockIdx.x - seq * a.H;
+  const int64_t row0 = (int64_t)seq * T;
+  const int64_t ld = 3 * (int64_t)D;
+  const int qcol = head * 64, kcol = D + head * 64, vcol = 2 * D + head * 64;
+
+  for (int e = tid; e < T * 64; e += 256) {
+    const int i = e >> 6, d = e & 63;
+    const int64_t g = (row0 + i) * ld + d;
+    q[i * BWD_LD + d] = ld_bf(a.qkv_hi, a.qkv_lo, g + qcol);
+    k[i * BWD_LD + d] = ld_bf(a.qkv_hi, a.qkv_lo, g + kcol);
+    v[i * BWD_LD + d] = ld_bf(a.qkv_hi, a.qkv_lo, g + vcol);
+    dO[i * BWD_LD + d] = ld_bf(a.dout_hi, a.dout_lo, (row0 + i) * D + head * 64 + d);
+  }
+  // delta_i = <dO_i, O_i>: one wave per row, O read straight from global
+  for (int i = wave; i < T; i += 4) {
+    const int64_t g = (row0 + i) * D + head * 64 + lane;
+    float s = ld_bf(a.dout_hi, a.dout_lo, g) * ld_bf(a.out_hi, a.out_lo, g);
+    s = wave_sum(s);
+    if (lane == 0) delta[i] = s;
+  }
+  __syncthreads();
+
+  // S
+  for (int e = tid; e < T * T; e += 256) {
+    const int i = e / T, j = e - i * T;
+    float s = 0.f;
+#pragma unroll 16
+    for (int d = 0; d < 64; ++d) s = fmaf(q[i * BWD_LD + d], k[j * BWD_LD + d], s);
+    if (a.causal && j > i) s = -INFINITY;
+    P[i * (T + 1) + j] = s;
+  }
+  __syncthreads();
+  // row softmax
+  for (int i = wave; i < T; i += 4) {
+    float mx = -INFINITY;
+    for (int j = lane; j < T; j += 64) mx = fmaxf(mx, P[i * (T + 1) + j]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < T; j += 64) {
+      const float p = expf(P[i * (T + 1) + j] - mx);
+      P[i * (T + 1) + j] = p;
+      sum += p;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int j = lane; j < T; j += 64) P[i * (T + 1) + j] *= inv;
+  }
+  __syncthreads();
+  // dV[j][d] = sum_i P[i][j] dO[i][d]
+  for (int e = tid; e < T * 64; e += 256) {
+    const int j = e >> 6, d = e & 63;
+    float s = 0.f;
+    for (int i = 0; i < T; ++i) s = fmaf(P[i * (T + 1) + j], dO[i * BWD_LD + d], s);
+    st_bf(a.dqkv_hi, a.dqkv_lo, (row0 + j) * ld + vcol + d, s);
+  }
+  __syncthreads();
+  // dS in place
+  for (int e = tid; e < T * T; e += 256) {
+    const int i = e / T, j = e - i * T;
+    float s = 0.f;
+#pragma unroll 16
+    for (int d = 0; d < 64; ++d) s = fmaf(dO[i * BWD_LD + d], v[j * BWD_LD + d], s);
+    P[i * (T + 1) + j] *= (s - delta[i]);
+  }
+  __syncthreads();
+  // dq[i][d] = sum_j dS[i][j] k[j][d];  dk[j][d] = sum_i dS[i][j] q[i][d]
+  for (int e = tid; e < T * 64; e += 256) {
+    const int i = e >> 6, d = e & 63;
+    float sq = 0.f, sk = 0.f;
+    for (int j = 0; j < T; ++j) {
+      sq = fmaf(P[i * (T + 1) + j], k[j * BWD_LD + d], sq);
+      sk = fmaf(P[j * (T + 1) + i], q[j * BWD_LD + d], sk);
+    }
+    st_bf(a.dqkv_hi, a.dqkv_lo, (row0 + i) * ld + qcol + d, sq);
+    st_bf(a.dqkv_hi, a.dqkv_lo, (row0 + i) * ld + kcol + d, sk);
+  }
+}
+
+// ---- LayerNorm backward fused with the residual-gradient add: dres[row] += dLN/dx (dy), one wave per row.
+// y = (x - mean) rstd gamma + beta;  g = dy gamma;  dx = rstd (g - mean(g) - xhat mean(g xhat))
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ dy, int64_t rows, int d, float* dres) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * d;
+  const float* gr = dy + row * d;
+  float s = 0.f;
+  for (int c = lane; c < d; c += 64) s += xr[c];
+  const float mean = wave_sum(s) / (float)d;
+  float ss = 0.f;
+  for (int c = lane; c < d; c += 64) {
+    const float t = xr[c] - mean;
+    ss += t * t;
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)d + 1e-5f);
+  float sg = 0.f, sgx = 0.f;
+  for (int c = lane; c < d; c += 64) {
+    const float g = gr[c] * gamma[c];
+    sg += g;
+    sgx += g * (xr[c] - mean) * rstd;
+  }
+  sg = wave_sum(sg) / (float)d;
+  sgx = wave_sum(sgx) / (float)d;
+  for (int c = lane; c < d; c += 64) {
+    const float xhat = (xr[c] - mean) * rstd;
+    dres[row * d + c] += rstd * (gr[c] * gamma[c] - sg - xhat * sgx);
+  }
+}
+
+// ---- d(pool -> project -> normalise): hidden row p (token tok of sequence n), y = p W, t = y/|y|.
+// dy = (dt - t <t, dt>) / |y|;  dp = dy W^T, written into d_hidden[n, tok, :] (other rows are zeroed by the caller).
+__global__ __launch_bounds__(256) void pool_project_bwd_kernel(const float* __restrict__ hidden, int tokens, int K,
+                                                               int tok_fixed, const float* __restrict__ proj, int E,
+                                                               int normalize, const float* __restrict__ dt,
+                                                               float* d_hidden) {
+  extern __shared__ float sh[];  // row[K] | y[E] | dy[E] | red[8]
+  float* row = sh;
+  float* y = sh + K;
+  float* dy = y + E;
+  float* red = dy + E;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t n = blockIdx.x;
+  int tok = tok_fixed;
+  if (tok < 0) tok += tokens;
+  const int64_t roff = (n * tokens + tok) * (int64_t)K;
+  for (int c = tid; c < K; c += 256) row[c] = hidden[roff + c];
+  __syncthreads();
+  for (int e = tid; e < E; e += 256) {
+    float s = 0.f;
+    for (int kk = 0; kk < K; ++kk) s = fmaf(row[kk], proj[(int64_t)kk * E + e], s);
+    y[e] = s;
+  }
+  __syncthreads();
+  if (normalize) {
+    float ss = 0.f, sd = 0.f;
+    for (int e = tid; e < E; e += 256) {
+      ss += y[e] * y[e];
+      sd += y[e] * dt[n * E + e];
+    }
+    ss = wave_sum(ss);
+    sd = wave_sum(sd);
+    if (lane == 0) {
+      red[wave] = ss;
+      red[4 + wave] = sd;
+    }
+    __syncthreads();
+    const float nrm2 = red[0] + red[1] + red[2] + red[3];
+    const float ydt = red[4] + red[5] + red[6] + red[7];
+    const float inv = 1.0f / sqrtf(nrm2);
+    for (int e = tid; e < E; e += 256) dy[e] = (dt[n * E + e] - y[e] * ydt / nrm2) * inv;
+  } else {
+    for (int e = tid; e < E; e += 256) dy[e] = dt[n * E + e];
+  }
+  __syncthreads();
+  for (int c = tid; c < K; c += 256) {
+    float s = 0.f;
+    const float* pr = proj + (int64_t)c * E;
+    for (int e = 0; e < E; ++e) s = fmaf(dy[e], pr[e], s);
+    d_hidden[roff + c] = s;
+  }
+}
+
+// ---- logits = scale * img txt^T:  d_txt[c,e] = scale * sum_b dl[b,c] img[b,e];  d(log scale) = sum dl * logits
+__global__ __launch_bounds__(256) void logits_bwd_txt_kernel(const float* __restrict__ dl, const float* __restrict__ img,
+                                                             float scale, int B, int C, int E, float* d_txt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)C * E) return;
+  const int c = (int)(i / E), e = (int)(i - (int64_t)c * E);
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s = fmaf(dl[(int64_t)b * C + c], img[(int64_t)b * E + e], s);
+  d_txt[i] = scale * s;
+}
+__global__ __launch_bounds__(256) void dot_reduce_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         int64_t n, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s = fmaf(a[i], b[i], s);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <bool SPLIT>
+__global__ void pack_transpose_kernel(const float* __restrict__ src, int64_t N, int K, int64_t scale_rows, float scale,
+                                      bf16_t* hi, bf16_t* lo) {
+  // dst[k][n] = src[n][k] (rows n < scale_rows scaled first)
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * K) return;
+  const int64_t kk = i / N, n = i - kk * N;
+  float v = src[n * K + kk];
+  if (n < scale_rows) v *= scale;
+  if (SPLIT) {
+    bf16_t h, l;
+    split_bf(v, h, l);
+    hi[i] = h;
+    lo[i] = l;
+  } else {
+    hi[i] = f2bf(v);
+  }
+}
+
+__global__ void fill_zero_kernel(float* p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
+inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+size_t attn_bwd_lds_bytes(int T) { return (size_t)(4 * T * BWD_LD + T * (T + 1) + T) * sizeof(float); }
+
+hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s) {
+  if (a.T <= 0 || a.T > 128 || a.D != a.H * 64 || a.n_seq <= 0) return hipErrorInvalidValue;
+  const size_t lds = attn_bwd_lds_bytes(a.T);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  static size_t attr = 0;
+  if (lds > attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr = lds;
+  }
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(a.n_seq * a.H)), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_ln_bwd(const float* x, const float* gamma, const float* dy, int64_t rows, int32_t d, float* dres,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, gamma, dy, rows, d, dres);
+  return hipGetLastError();
+}
+
+hipError_t launch_pool_project_bwd(const float* hidden, int64_t n, int32_t tokens, int32_t K, int32_t tok,
+                                   const float* proj, int32_t E, int32_t normalize, const float* dt, float* d_hidden,
+                                   hipStream_t s) {
+  hipLaunchKernelGGL(fill_zero_kernel, dim3(nblk(n * tokens * K)), dim3(256), 0, s, d_hidden, n * tokens * K);
+  hipLaunchKernelGGL(pool_project_bwd_kernel, dim3((unsigned)n), dim3(256), (K + 2 * E + 8) * sizeof(float), s, hidden,
+                     tokens, K, tok, proj, E, normalize, dt, d_hidden);
+  return hipGetLastError();
+}
+
+hipError_t launch_logits_bwd(const float* dl, const float* logits, const float* img, float scale, int32_t B, int32_t C,
+                             int32_t E, float* d_txt, float* d_logscale, hipStream_t s) {
+  hipLaunchKernelGGL(logits_bwd_txt_kernel, dim3(nblk((int64_t)C * E)), dim3(256), 0, s, dl, img, scale, B, C, E, d_txt);
+  if (d_logscale) hipLaunchKernelGGL(dot_reduce_kernel, dim3(1), dim3(256), 0, s, dl, logits, (int64_t)B * C, d_logscale);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_transpose(const float* src, int64_t N, int32_t K, int64_t scale_rows, float scale, bf16_t* hi,
+                                 bf16_t* lo, hipStream_t s) {
+  if (lo) hipLaunchKernelGGL((pack_transpose_kernel<true>), dim3(nblk(N * K)), dim3(256), 0, s, src, N, K, scale_rows, scale, hi, lo);
+  else hipLaunchKernelGGL((pack_transpose_kernel<false>), dim3(nblk(N * K)), dim3(256), 0, s, src, N, K, scale_rows, scale, hi, lo);
+  return hipGetLastError();
+}
+
+}  // namespace tapclip

@@ -66,6 +66,16 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
   const float e = __builtin_amdgcn_exp2f(p * xc);
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
+// derivatives (backward of c_fc's activation); the bf16 forward uses the fitted GELU, whose derivative
+// differs from the exact one by < 2e-4
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f));
+  return fmaf(x * 0.3989422804014327f, __expf(-0.5f * x * x), cdf);
+}
+__device__ __forceinline__ float gelu_quick_grad(float x) {
+  const float s = 1.0f / (1.0f + __expf(-1.702f * x));
+  return s * (1.0f + 1.702f * x * (1.0f - s));
+}
 __device__ __forceinline__ float gelu_quick(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 
 }  // namespace tapclip

@@ -171,7 +171,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
           for (int e = 0; e < 4; ++e) v[e] = gelu_quick(v[e]);
         }
       }
-      if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16) {
+      if (EPI == EPI_GELU_BWD_BF16) {
+        const int64_t o = orow * g.ldo + n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float up = bf2f(g.aux_hi[o + e]);
+          if (SPLIT) up += bf2f(g.aux_lo[o + e]);
+          v[e] = (g.act == 0 ? gelu_erf_grad(v[e]) : gelu_quick_grad(v[e])) * up;
+        }
+      }
+      if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_GELU_BWD_BF16) {
         bf16_t h[4], l[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -242,6 +251,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, bool split, hipStream_t 
     TAPCLIP_GEMM_CASE(EPI_BIAS_RESID_F32)
     TAPCLIP_GEMM_CASE(EPI_PATCH_F32)
     TAPCLIP_GEMM_CASE(EPI_BIAS_F32)
+    TAPCLIP_GEMM_CASE(EPI_GELU_BWD_BF16)
     default:
       return hipErrorInvalidValue;
   }

@@ -238,7 +238,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
   };
 
   auto epilogue = [&](int64_t m0, int n0) {
-    if (g.act == 99) return;  // gemm_bench NOSTORE experiment
     if (TR_EPI) {
       // lane (r, q) holds, per 16-row block i and sub-tile j, 4 consecutive n of row 16 i + r.  Write the
       // block as [16 rows][BN/4 bf16] (16-B chunk c of row rr at slot c ^ (rr & 7): conflict-free both
@@ -334,7 +333,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
           for (int e = 0; e < 4; ++e) v[e] = gelu_quick(v[e]);
         }
       }
-      if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16) {
+      if (EPI == EPI_GELU_BWD_BF16) {
+        const int64_t o = orow * g.ldo + n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float up = bf2f(g.aux_hi[o + e]);
+          if (SPLIT) up += bf2f(g.aux_lo[o + e]);
+          v[e] = (g.act == 0 ? gelu_erf_grad(v[e]) : gelu_quick_grad(v[e])) * up;
+        }
+      }
+      if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_GELU_BWD_BF16) {
         bf16_t h[4], l[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -483,6 +491,7 @@ hipError_t launch_gemm256(const GemmArgs& a, int epilogue, bool split, hipStream
     case EPI_BIAS_RESID_F32: return launch_e<EPI_BIAS_RESID_F32>(a, split, s);
     case EPI_PATCH_F32: return launch_e<EPI_PATCH_F32>(a, split, s);
     case EPI_BIAS_F32: return launch_e<EPI_BIAS_F32>(a, split, s);
+    case EPI_GELU_BWD_BF16: return launch_e<EPI_GELU_BWD_BF16>(a, split, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -13,6 +13,7 @@ enum Epilogue {
   EPI_BIAS_RESID_F32 = 2,  // out_f32[m,n] += acc + bias[n]   (in-place residual add)     (out_proj K5, c_proj K7)
   EPI_PATCH_F32 = 3,       // out_f32[b*(G2+1)+1+p, n] = acc + add_table[(1+p), n]        (patch embed, K1)
   EPI_BIAS_F32 = 4,        // out_f32[m,n] = acc + bias[n]   (unit API / literal hook attn_out)
+  EPI_GELU_BWD_BF16 = 5,   // out_hi(/lo)[m,n] = bf16(act'(acc + bias[n]) * aux[m,n])   (backward of c_fc's GELU)
 };
 
 struct GemmArgs {
@@ -31,6 +32,8 @@ struct GemmArgs {
   const float* add_table;  // EPI_PATCH_F32: positional embedding [(G2+1), N]
   int32_t rows_per_group;  // EPI_PATCH_F32: G2 patches per image
   int32_t act;             // TAPCLIP_ACT_*
+  const bf16_t* aux_hi = nullptr;  // EPI_GELU_BWD_BF16: upstream gradient dL/dh [M, N] (row stride ldo); may alias out
+  const bf16_t* aux_lo = nullptr;
 };
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, bool split, hipStream_t s);
@@ -80,6 +83,30 @@ hipError_t launch_pool_project(const float* src, const bf16_t* delta_hi, const b
                                int32_t tokens, int32_t K, const int64_t* index, int32_t fixed_token,
                                const float* ln_g, const float* ln_b, const float* proj, int32_t E,
                                int32_t normalize, float* out, hipStream_t s);
+
+// ---- backward (prompt tuning): see backward.hip
+struct AttnBwdArgs {
+  const bf16_t* qkv_hi;   // saved forward q|k|v [n*T, 3D]
+  const bf16_t* qkv_lo;
+  const bf16_t* out_hi;   // saved forward attention output [n*T, D]
+  const bf16_t* out_lo;
+  const bf16_t* dout_hi;  // dL/d(attention output) [n*T, D]
+  const bf16_t* dout_lo;
+  bf16_t* dqkv_hi;        // [n*T, 3D]
+  bf16_t* dqkv_lo;
+  int32_t n_seq, T, H, D, causal;
+};
+size_t attn_bwd_lds_bytes(int T);
+hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s);
+hipError_t launch_ln_bwd(const float* x, const float* gamma, const float* dy, int64_t rows, int32_t d, float* dres,
+                         hipStream_t s);
+hipError_t launch_pool_project_bwd(const float* hidden, int64_t n, int32_t tokens, int32_t K, int32_t tok,
+                                   const float* proj, int32_t E, int32_t normalize, const float* dt, float* d_hidden,
+                                   hipStream_t s);
+hipError_t launch_logits_bwd(const float* dl, const float* logits, const float* img, float scale, int32_t B, int32_t C,
+                             int32_t E, float* d_txt, float* d_logscale, hipStream_t s);
+hipError_t launch_pack_transpose(const float* src, int64_t N, int32_t K, int64_t scale_rows, float scale, bf16_t* hi,
+                                 bf16_t* lo, hipStream_t s);
 
 hipError_t launch_embed_tokens(const float* table, int32_t vocab, const float* pos, const int64_t* tokens,
                                int32_t n, int32_t L, int32_t D, int32_t add_pos, float* out, hipStream_t s);

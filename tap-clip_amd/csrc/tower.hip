@@ -54,6 +54,7 @@ struct Packed {  // a [rows, ld] bf16 matrix (hi, and lo for bf16x3)
 struct LayerW {
   float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
   Packed wqkv, wo, wfc, wpr;
+  Packed wqkv_t, wo_t, wfc_t, wpr_t;  // text towers: transposed copies [K, N] for the dX GEMMs of the backward
   float *bqkv = nullptr, *bo = nullptr, *bfc = nullptr, *bpr = nullptr;
 };
 
@@ -207,8 +208,10 @@ std::string shape_str(const int64_t* shape, int ndim) {
 
 int gemm(tapclip_tower* t, int slot, int epi, const bf16_t* a_hi, const bf16_t* a_lo, int64_t lda, const Packed& w,
          const float* bias, int64_t M, int N, int K, bf16_t* o_hi, bf16_t* o_lo, float* o_f32, int64_t ldo,
-         hipStream_t s, const float* add_table = nullptr, int rows_per_group = 0) {
+         hipStream_t s, const float* add_table = nullptr, int rows_per_group = 0, const bf16_t* aux_hi = nullptr,
+         const bf16_t* aux_lo = nullptr) {
   GemmArgs g;
+  g.aux_hi = aux_hi; g.aux_lo = aux_lo;
   g.A_hi = a_hi; g.A_lo = a_lo; g.lda = lda;
   g.W_hi = w.hi; g.W_lo = w.lo;
   g.bias = bias;
@@ -264,6 +267,92 @@ int run_blocks(tapclip_tower* t, float* x, int64_t n_seq, int tokens, int causal
     if (rc) return rc;
     rc = gemm(t, 6, EPI_BIAS_BF16, w.h_hi, w.h_lo, F, L.wpr, L.bpr, M, D, F, w.d_hi, w.d_lo, nullptr, D, s);
     if (rc) return rc;
+  }
+  return TAPCLIP_OK;
+}
+
+// ---- saved activations of the recomputed forward (backward only)
+struct Saved {
+  std::vector<float*> x0, x1;
+  std::vector<bf16_t*> qkv_hi, qkv_lo, ao_hi, ao_lo;
+  size_t bytes = 0;
+};
+
+Saved carve_saved(const tapclip_tower* t, int64_t M, void* base) {
+  Saved sv;
+  const int64_t D = t->cfg.width;
+  const int L = t->cfg.layers;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    void* p = base ? static_cast<char*>(base) + off : nullptr;
+    off += align_up(bytes);
+    return p;
+  };
+  for (int l = 0; l < L; ++l) {
+    sv.x0.push_back(static_cast<float*>(take(M * D * 4)));
+    sv.x1.push_back(static_cast<float*>(take(M * D * 4)));
+    sv.qkv_hi.push_back(static_cast<bf16_t*>(take(M * 3 * D * 2)));
+    sv.ao_hi.push_back(static_cast<bf16_t*>(take(M * D * 2)));
+    sv.qkv_lo.push_back(t->split ? static_cast<bf16_t*>(take(M * 3 * D * 2)) : nullptr);
+    sv.ao_lo.push_back(t->split ? static_cast<bf16_t*>(take(M * D * 2)) : nullptr);
+  }
+  sv.bytes = off;
+  return sv;
+}
+
+// Forward of the text tower again, keeping what the backward needs (activation recomputation keeps the C ABI
+// stateless: nothing is remembered between tapclip_text_forward and tapclip_text_backward), then the
+// backward sweep.  dx (fp32 [M, D]) enters holding dL/d(hidden) and leaves holding dL/d(x_in).
+int run_backward(tapclip_tower* t, const float* x_in, float* dx, int64_t n_seq, int tokens, int causal,
+                 const Workspace& w, const Saved& sv, hipStream_t s) {
+  const int64_t M = n_seq * tokens;
+  const int D = t->cfg.width, F = t->cfg.mlp_dim, H = t->cfg.heads, L = t->cfg.layers;
+  float* x = w.x;
+  HIP_TRY(hipMemcpyAsync(x, x_in, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
+  auto keep = [&](float* dst) { return hipMemcpyAsync(dst, x, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s); };
+  int rc;
+  for (int li = 0; li < L; ++li) {
+    const LayerW& Lw = t->layers[li];
+    if (li == 0) HIP_TRY(launch_layernorm(x, D, Lw.ln1_g, Lw.ln1_b, M, D, w.xn_hi, w.xn_lo, nullptr, s));
+    else HIP_TRY(launch_add_layernorm(x, w.d_hi, w.d_lo, Lw.ln1_g, Lw.ln1_b, M, D, w.xn_hi, w.xn_lo, s));
+    HIP_TRY(keep(sv.x0[li]));
+    if ((rc = gemm(t, 2, EPI_BIAS_BF16, w.xn_hi, w.xn_lo, D, Lw.wqkv, Lw.bqkv, M, 3 * D, D, sv.qkv_hi[li], sv.qkv_lo[li], nullptr, 3 * D, s))) return rc;
+    AttnArgs a;
+    a.qkv_hi = sv.qkv_hi[li]; a.qkv_lo = sv.qkv_lo[li];
+    a.out_hi = sv.ao_hi[li]; a.out_lo = sv.ao_lo[li];
+    a.probs = nullptr;
+    a.n_seq = (int)n_seq; a.T = tokens; a.H = H; a.D = D; a.causal = causal;
+    HIP_TRY(launch_attention(a, t->split, s));
+    if ((rc = gemm(t, 4, EPI_BIAS_BF16, sv.ao_hi[li], sv.ao_lo[li], D, Lw.wo, Lw.bo, M, D, D, w.d_hi, w.d_lo, nullptr, D, s))) return rc;
+    HIP_TRY(launch_add_layernorm(x, w.d_hi, w.d_lo, Lw.ln2_g, Lw.ln2_b, M, D, w.xn_hi, w.xn_lo, s));
+    HIP_TRY(keep(sv.x1[li]));
+    if ((rc = gemm(t, 5, EPI_BIAS_GELU_BF16, w.xn_hi, w.xn_lo, D, Lw.wfc, Lw.bfc, M, F, D, w.h_hi, w.h_lo, nullptr, F, s))) return rc;
+    if ((rc = gemm(t, 6, EPI_BIAS_BF16, w.h_hi, w.h_lo, F, Lw.wpr, Lw.bpr, M, D, F, w.d_hi, w.d_lo, nullptr, D, s))) return rc;
+  }
+  // ---- backward sweep.  Scratch re-uses the forward workspace: g = w.d (branch gradient as a GEMM operand),
+  // w.h = dL/dh then dL/dz, w.ao = dL/d(attention out), w.qkv = dL/d(qkv), w.x = fp32 dL/d(LN output)
+  float* dn = w.x;
+  for (int li = L - 1; li >= 0; --li) {
+    const LayerW& Lw = t->layers[li];
+    // MLP branch: m = gelu(LN2(x1) Wfc^T + bfc) Wpr^T + bpr
+    HIP_TRY(launch_pack(dx, M, D, D, D, 0, 1.f, w.d_hi, w.d_lo, s));
+    if ((rc = gemm(t, 6, EPI_BIAS_BF16, w.d_hi, w.d_lo, D, Lw.wpr_t, nullptr, M, F, D, w.h_hi, w.h_lo, nullptr, F, s))) return rc;
+    HIP_TRY(launch_layernorm(sv.x1[li], D, Lw.ln2_g, Lw.ln2_b, M, D, w.xn_hi, w.xn_lo, nullptr, s));
+    if ((rc = gemm(t, 5, EPI_GELU_BWD_BF16, w.xn_hi, w.xn_lo, D, Lw.wfc, Lw.bfc, M, F, D, w.h_hi, w.h_lo, nullptr, F, s, nullptr, 0, w.h_hi, w.h_lo))) return rc;
+    if ((rc = gemm(t, 5, EPI_BIAS_F32, w.h_hi, w.h_lo, F, Lw.wfc_t, nullptr, M, D, F, nullptr, nullptr, dn, D, s))) return rc;
+    HIP_TRY(launch_ln_bwd(sv.x1[li], Lw.ln2_g, dn, M, D, dx, s));
+    // attention branch: a = attention(LN1(x0) Wqkv^T + b) Wo^T + bo
+    HIP_TRY(launch_pack(dx, M, D, D, D, 0, 1.f, w.d_hi, w.d_lo, s));
+    if ((rc = gemm(t, 4, EPI_BIAS_BF16, w.d_hi, w.d_lo, D, Lw.wo_t, nullptr, M, D, D, w.ao_hi, w.ao_lo, nullptr, D, s))) return rc;
+    AttnBwdArgs b;
+    b.qkv_hi = sv.qkv_hi[li]; b.qkv_lo = sv.qkv_lo[li];
+    b.out_hi = sv.ao_hi[li]; b.out_lo = sv.ao_lo[li];
+    b.dout_hi = w.ao_hi; b.dout_lo = w.ao_lo;
+    b.dqkv_hi = w.qkv_hi; b.dqkv_lo = w.qkv_lo;
+    b.n_seq = (int)n_seq; b.T = tokens; b.H = H; b.D = D; b.causal = causal;
+    HIP_TRY(launch_attention_bwd(b, s));
+    if ((rc = gemm(t, 2, EPI_BIAS_F32, w.qkv_hi, w.qkv_lo, 3 * D, Lw.wqkv_t, nullptr, M, D, 3 * D, nullptr, nullptr, dn, D, s))) return rc;
+    HIP_TRY(launch_ln_bwd(sv.x0[li], Lw.ln1_g, dn, M, D, dx, s));
   }
   return TAPCLIP_OK;
 }
@@ -359,26 +448,35 @@ int tapclip_tower_load_weight(tapclip_tower_t* t, const char* key_c, const float
     const int li = atoi(key.substr(pre.size(), dot - pre.size()).c_str());
     const std::string sub = key.substr(dot + 1);
     LayerW& L = t->layers[li];
-    auto vec = [&](int64_t n, float** dst, int64_t scale_n = 0, float scale = 1.f) {
+    auto vec = [&](int64_t n, float** dst, int64_t scale_n = 0, float scale = 1.f) -> int {
       if (!shape_is(shape, ndim, {n})) return bad(("[" + std::to_string(n) + "]").c_str());
       return own_f32(t, src, n, scale_n, scale, dst, s);
     };
-    auto mat = [&](int64_t rows, int64_t cols, Packed* dst, int64_t scale_rows = 0, float scale = 1.f) {
+    auto mat = [&](int64_t rows, int64_t cols, Packed* dst, Packed* dst_t, int64_t scale_rows = 0, float scale = 1.f) -> int {
       if (!shape_is(shape, ndim, {rows, cols})) return bad(("[" + std::to_string(rows) + "," + std::to_string(cols) + "]").c_str());
-      return own_packed(t, src, rows, (int)cols, (int)cols, scale_rows, scale, dst, s);
+      int r = own_packed(t, src, rows, (int)cols, (int)cols, scale_rows, scale, dst, s);
+      if (r || t->cfg.kind != TAPCLIP_TOWER_TEXT) return r;
+      // W^T [cols, rows] for dX = dY . W (only the text tower is ever differentiated)
+      void *h, *l = nullptr;
+      if ((r = dev_alloc(t, rows * cols * 2, &h))) return r;
+      if (t->split && (r = dev_alloc(t, rows * cols * 2, &l))) return r;
+      HIP_TRY(launch_pack_transpose(src, rows, (int)cols, scale_rows, scale, static_cast<bf16_t*>(h), static_cast<bf16_t*>(l), s));
+      dst_t->hi = static_cast<bf16_t*>(h);
+      dst_t->lo = static_cast<bf16_t*>(l);
+      return TAPCLIP_OK;
     };
     const float qscale = 1.0f / sqrtf(64.0f);  // folded softmax scale; exact in bf16
     if (sub == "ln_1.weight") rc = vec(D, &L.ln1_g);
     else if (sub == "ln_1.bias") rc = vec(D, &L.ln1_b);
     else if (sub == "ln_2.weight") rc = vec(D, &L.ln2_g);
     else if (sub == "ln_2.bias") rc = vec(D, &L.ln2_b);
-    else if (sub == "attn.in_proj_weight") rc = mat(3 * D, D, &L.wqkv, D, qscale);
+    else if (sub == "attn.in_proj_weight") rc = mat(3 * D, D, &L.wqkv, &L.wqkv_t, D, qscale);
     else if (sub == "attn.in_proj_bias") rc = vec(3 * D, &L.bqkv, D, qscale);
-    else if (sub == "attn.out_proj.weight") rc = mat(D, D, &L.wo);
+    else if (sub == "attn.out_proj.weight") rc = mat(D, D, &L.wo, &L.wo_t);
     else if (sub == "attn.out_proj.bias") rc = vec(D, &L.bo);
-    else if (sub == "mlp.c_fc.weight") rc = mat(F, D, &L.wfc);
+    else if (sub == "mlp.c_fc.weight") rc = mat(F, D, &L.wfc, &L.wfc_t);
     else if (sub == "mlp.c_fc.bias") rc = vec(F, &L.bfc);
-    else if (sub == "mlp.c_proj.weight") rc = mat(D, F, &L.wpr);
+    else if (sub == "mlp.c_proj.weight") rc = mat(D, F, &L.wpr, &L.wpr_t);
     else if (sub == "mlp.c_proj.bias") rc = vec(D, &L.bpr);
     else return fail(TAPCLIP_EINVAL, "unexpected key '%s'", key_c);
   } else if (t->cfg.kind == TAPCLIP_TOWER_VISION) {
@@ -489,6 +587,47 @@ int tapclip_text_forward(tapclip_tower_t* t, const float* x_in, int32_t n_seq, i
   if (rc) return rc;
   if (out_hidden) HIP_TRY(launch_add_delta(x, w.d_hi, w.d_lo, (int64_t)n_seq * tokens * D, s));  // last pending branch
   if (attn_mean) HIP_TRY(launch_head_mean(probs, n_seq, t->cfg.heads, tokens, attn_mean, s));
+  return TAPCLIP_OK;
+}
+
+size_t tapclip_text_backward_workspace_bytes(const tapclip_tower_t* t, int64_t n_seq, int32_t tokens) {
+  if (!t || n_seq <= 0 || tokens <= 0 || t->cfg.kind != TAPCLIP_TOWER_TEXT) return 0;
+  return align_up(carve(t, n_seq, tokens, nullptr).bytes) + carve_saved(t, n_seq * tokens, nullptr).bytes;
+}
+
+int tapclip_text_backward(tapclip_tower_t* t, const float* x_in, const float* grad_hidden, int32_t n_seq, int32_t tokens,
+                          int32_t causal, float* grad_x, void* workspace, size_t workspace_bytes, tapclip_stream_t stream) {
+  if (!t || !x_in || !grad_hidden || !grad_x || !workspace) return fail(TAPCLIP_EINVAL, "null argument");
+  if (t->cfg.kind != TAPCLIP_TOWER_TEXT) return fail(TAPCLIP_EINVAL, "text_backward needs a text tower");
+  if (n_seq <= 0 || tokens <= 0) return fail(TAPCLIP_EINVAL, "bad n_seq/tokens");
+  if (attn_bwd_lds_bytes(tokens) > 160 * 1024) return fail(TAPCLIP_EINVAL, "text_backward supports at most ~105 tokens per sequence (got %d)", tokens);
+  int rc = check_ready(t);
+  if (rc) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const Workspace w = carve(t, n_seq, tokens, workspace);
+  const size_t off = align_up(w.bytes);
+  const Saved sv = carve_saved(t, (int64_t)n_seq * tokens, static_cast<char*>(workspace) + off);
+  if (off + sv.bytes > workspace_bytes) return fail(TAPCLIP_EWORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, off + sv.bytes);
+  if (grad_x != grad_hidden)
+    HIP_TRY(hipMemcpyAsync(grad_x, grad_hidden, (size_t)n_seq * tokens * t->cfg.width * 4, hipMemcpyDeviceToDevice, s));
+  return run_backward(t, x_in, grad_x, n_seq, tokens, causal, w, sv, s);
+}
+
+int tapclip_text_pool_project_backward(tapclip_tower_t* t, const float* hidden, int32_t n_seq, int32_t tokens, int32_t normalize,
+                                       const float* grad_out, float* grad_hidden, tapclip_stream_t stream) {
+  if (!t || !hidden || !grad_out || !grad_hidden) return fail(TAPCLIP_EINVAL, "null argument");
+  if (t->cfg.kind != TAPCLIP_TOWER_TEXT) return fail(TAPCLIP_EINVAL, "needs a text tower");
+  int rc = check_ready(t);
+  if (rc) return rc;
+  HIP_TRY(launch_pool_project_bwd(hidden, n_seq, tokens, t->cfg.width, -1, t->text_proj, t->cfg.embed_dim, normalize, grad_out,
+                                  grad_hidden, static_cast<hipStream_t>(stream)));
+  return TAPCLIP_OK;
+}
+
+int tapclip_logits_backward(const float* grad_logits, const float* logits, const float* img, float scale, int32_t B, int32_t C,
+                            int32_t E, float* grad_txt, float* grad_log_scale, tapclip_stream_t stream) {
+  if (!grad_logits || !logits || !img || !grad_txt || B <= 0 || C <= 0 || E <= 0) return fail(TAPCLIP_EINVAL, "bad logits_backward arguments");
+  HIP_TRY(launch_logits_bwd(grad_logits, logits, img, scale, B, C, E, grad_txt, grad_log_scale, static_cast<hipStream_t>(stream)));
   return TAPCLIP_OK;
 }
 

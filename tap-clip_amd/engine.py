@@ -165,6 +165,33 @@ class TextTower(_Tower):
                                                           int(normalize), _ptr(out), _stream_ptr(self.device)))
         return out
 
+    # -- prompt-tuning backward (dX only; reference train.py:99-105) ---------------------------------
+    def backward(self, x: torch.Tensor, grad_hidden: torch.Tensor, causal: bool = False) -> torch.Tensor:
+        """dL/dx of `forward(x)["hidden"]` given dL/d(hidden); recomputes the forward internally."""
+        xin = _dev_f32(x, self.device)
+        g = _dev_f32(grad_hidden, self.device)
+        n, T, D = xin.shape
+        out = torch.empty_like(xin)
+        with torch.cuda.device(self.device):
+            need = int(self.lib.tapclip_text_backward_workspace_bytes(self.handle, n, T))
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = None
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            _lib.check(self.lib.tapclip_text_backward(self.handle, _ptr(xin), _ptr(g), n, T, int(causal), _ptr(out),
+                                                      _ptr(self._ws), self._ws.numel(), _stream_ptr(self.device)))
+        return out
+
+    def pool_project_backward(self, hidden: torch.Tensor, grad_out: torch.Tensor, normalize: bool = True) -> torch.Tensor:
+        """backward of `pool_project(hidden, index=None, ln_final=False, normalize)`: [n,E] -> [n,T,D]."""
+        h = _dev_f32(hidden, self.device)
+        g = _dev_f32(grad_out, self.device)
+        n, T, _ = h.shape
+        out = torch.empty_like(h)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.tapclip_text_pool_project_backward(self.handle, _ptr(h), n, T, int(normalize), _ptr(g),
+                                                                   _ptr(out), _stream_ptr(self.device)))
+        return out
+
     def embed_tokens(self, tokens: torch.Tensor, add_pos: bool) -> torch.Tensor:
         t = tokens.to(device=self.device, dtype=torch.int64).contiguous()
         if t.dim() != 2:
@@ -215,6 +242,21 @@ def logits(img: torch.Tensor, txt: torch.Tensor, scale: float) -> torch.Tensor:
     with torch.cuda.device(i.device):
         _lib.check(_lib.load().tapclip_logits(_ptr(i), _ptr(t), float(scale), B, Cn, E, _ptr(out), _stream_ptr(i.device)))
     return out
+
+
+def logits_backward(grad_logits: torch.Tensor, logits_out: torch.Tensor, img: torch.Tensor, scale: float):
+    """(d_txt [C,E], d_log_scale []) of `logits(img, txt, scale)` with scale = exp(log_scale)."""
+    gl = grad_logits.detach().to(torch.float32).contiguous()
+    lo = logits_out.detach().to(torch.float32).contiguous()
+    i = img.detach().to(torch.float32).contiguous()
+    B, Cn = gl.shape
+    E = i.shape[1]
+    d_txt = torch.empty(Cn, E, dtype=torch.float32, device=gl.device)
+    d_ls = torch.empty((), dtype=torch.float32, device=gl.device)
+    with torch.cuda.device(gl.device):
+        _lib.check(_lib.load().tapclip_logits_backward(_ptr(gl), _ptr(lo), _ptr(i), float(scale), B, Cn, E, _ptr(d_txt),
+                                                       _ptr(d_ls), _stream_ptr(gl.device)))
+    return d_txt, d_ls
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:

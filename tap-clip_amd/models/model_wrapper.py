@@ -30,6 +30,43 @@ from .prompt_adjustor import PromptAdjustor
 from .prompt_learner import PromptLearner
 
 
+class _TextTowerFn(torch.autograd.Function):
+    """prompts [n,T,D] -> L2-normalised text features [n,E] (reference model_wrapper.py:72-75) with a HIP
+    backward: d(pool, projection, norm) and dX through the 12 frozen blocks (`tapclip_text_backward`)."""
+
+    @staticmethod
+    def forward(ctx, prompts, clip):
+        tower = clip._text
+        hidden = clip.model.transformer(prompts.detach())
+        ctx.tower = tower
+        ctx.save_for_backward(prompts.detach(), hidden)
+        return tower.pool_project(hidden, index=None, ln_final=False, normalize=True)
+
+    @staticmethod
+    def backward(ctx, grad_feat):
+        prompts, hidden = ctx.saved_tensors
+        g_hidden = ctx.tower.pool_project_backward(hidden, grad_feat.contiguous(), normalize=True)
+        return ctx.tower.backward(prompts, g_hidden), None
+
+
+class _LogitsFn(torch.autograd.Function):
+    """exp(logit_scale) * img @ txt.T (reference model_wrapper.py:79,83); img carries no gradient (frozen tower)."""
+
+    @staticmethod
+    def forward(ctx, img, txt, log_scale):
+        scale = float(log_scale.detach().exp())
+        out = engine.logits(img, txt, scale)
+        ctx.scale = scale
+        ctx.save_for_backward(img, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_logits):
+        img, out = ctx.saved_tensors
+        d_txt, d_ls = engine.logits_backward(grad_logits.contiguous(), out, img, ctx.scale)
+        return None, d_txt, d_ls
+
+
 class FullModel(nn.Module):
     def __init__(self, class_names, clip_wrapper, prompt_len=5, attr_lambda=1.0, stab_lambda=0.1,
                  adjustor_method='scale', class_specific=False, *, collapse_text: bool = True,
@@ -101,11 +138,38 @@ class FullModel(nn.Module):
         return torch.cat(sims, dim=1)
 
     # ---- forward -------------------------------------------------------------------------------
+    def _forward_train(self, images, labels):
+        """Differentiable forward (reference train.py:99-105): gradients reach `context_bank.*` (and any
+        trainable PromptAdjustor net) and `logit_scale`; the attention capture is a constant, as the
+        reference's hook detaches it (clip_wrapper.py:36)."""
+        pl, clip = self.prompt_learner, self.clip
+        with torch.no_grad():
+            image_feat = clip._vision.encode_image(images, normalize=True)
+            if self.gather_images:
+                from ..dist import all_gather_rows
+                image_feat = all_gather_rows(image_feat)
+            ctx_c, tok = pl.stacked_context().detach(), pl.stacked_tokens()
+            clip.reset()
+            clip.model.transformer(engine.build_prompts(ctx_c, tok))
+            attn_map = clip.get_attention_map()
+            if attn_map.dim() == 2:
+                attn_map = attn_map.unsqueeze(1)
+            attribution = self.attribution_monitor(attn_map)
+        ctx = pl.stacked_context()                                   # differentiable w.r.t. every context_bank entry
+        adjusted = torch.cat([self.prompt_adjustor(ctx, attribution), tok], dim=1)
+        text_feat = _TextTowerFn.apply(adjusted, clip)
+        logits = _LogitsFn.apply(image_feat, text_feat, self.logit_scale)
+        self.last_attribution = attribution
+        outputs = {"logits": logits}
+        if labels is not None:
+            loss_cls = F.cross_entropy(logits, labels.to(logits.device))
+            outputs.update({"loss": loss_cls, "loss_cls": loss_cls})
+        return outputs
+
     def forward(self, images, labels=None):
-        if torch.is_grad_enabled() and labels is not None and any(p.requires_grad for p in self.prompt_learner.parameters()):
-            raise NotImplementedError(
-                "prompt-tuning backward (dX through the text tower) is not built yet: SURVEY.md section 8f row 1. "
-                "Call under torch.no_grad() for inference / evaluation.")
+        if torch.is_grad_enabled() and self.collapse_text and (
+                self.logit_scale.requires_grad or any(p.requires_grad for p in self.prompt_learner.parameters())):
+            return self._forward_train(images, labels)
         with torch.no_grad():
             if not self.collapse_text:
                 logits = self._forward_literal(images)

@@ -286,6 +286,69 @@ def test_fullmodel_tiny_vs_reference(semantics, precision):
 
 
 @pytest.mark.parametrize("semantics", ["literal", "intended"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_fullmodel_backward_vs_reference(semantics, precision):
+    """loss.backward() of the reference FullModel (train.py:99-105): gradients of every context_bank entry
+    and of logit_scale, from the goldens."""
+    g = golden(f"fullmodel_{semantics}_tiny")
+    model, images = _build_full("tiny", g, semantics, precision)
+    model.train()
+    out = model(images, torch.from_numpy(g["labels"]).to(DEV))
+    assert out["logits"].requires_grad
+    out["loss"].backward()
+    names = g["class_names"].tolist()
+    grad = torch.stack([model.prompt_learner.context_bank[c].grad for c in names], 0).cpu()
+    ref = torch.from_numpy(g["context_grad"])
+    _report(f"FullModel tiny {semantics} {precision} context grad", grad, ref)
+    tol = TOL if precision == "bf16x3" else 5e-2
+    assert rel_max(grad, ref) < tol and rel_l2(grad, ref) < tol
+    assert abs(float(model.logit_scale.grad) - float(g["logit_scale_grad"])) < tol * max(1.0, abs(float(g["logit_scale_grad"])))
+    assert abs(float(out["loss"]) - float(g["loss"])) < tol * max(1.0, abs(float(g["loss"])))
+    assert all(p.grad is None for p in model.clip.parameters())  # CLIP stays frozen
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_text_backward_real_dims_vs_oracle_autograd(eng, precision):
+    """dX through the ViT-B text tower (d=512, 12 blocks, T = 16 + 77 = 93) against torch autograd through
+    the CPU oracle, for a gradient that enters at token -1 like FullModel's."""
+    cfg = configs.get_config("ViT-B-16")
+    sd = synth.make_state_dict(cfg, seed=2, vision=False)
+    tower = eng.TextTower(cfg, sd, DEV, precision)
+    n, T, D = 6, 93, 512
+    x = torch.cat([synth.normal([n, 16, D], 4, "bwd.ctx"), synth.normal([n, 77, D], 4, "bwd.tok", 0.02)], dim=1)
+    gfeat = synth.normal([n, 512], 4, "bwd.g")
+    xr = x.clone().requires_grad_(True)
+    hidden, _, _ = clip_ref.text_transformer_raw(xr, sd, clip_ref.CONFIGS["ViT-B-16"])
+    feat = hidden[:, -1, :] @ sd["text_projection"]
+    feat = feat / feat.norm(dim=-1, keepdim=True)
+    (feat * gfeat).sum().backward()
+    hid = tower.forward(x.to(DEV))["hidden"]
+    g_hidden = tower.pool_project_backward(hid, gfeat.to(DEV), normalize=True)
+    gx = tower.backward(x.to(DEV), g_hidden).cpu()
+    _report(f"text backward real dims {precision} dL/dx", gx, xr.grad)
+    tol = TOL if precision == "bf16x3" else 5e-2
+    assert rel_l2(gx, xr.grad) < tol
+    assert rel_max(gx[:, :16], xr.grad[:, :16]) < tol  # the context-token rows FullModel uses
+
+
+def test_train_step_reduces_loss():
+    """A few AdamW steps on context_bank only (reference train.py:65-67,99-105) lower the loss."""
+    g = golden("fullmodel_intended_tiny")
+    model, images = _build_full("tiny", g, "intended", "bf16")
+    labels = torch.from_numpy(g["labels"]).to(DEV)
+    opt = torch.optim.AdamW(model.prompt_learner.parameters(), lr=2e-3, weight_decay=0.01)
+    model.train()
+    losses = []
+    for _ in range(8):
+        out = model(images, labels)
+        opt.zero_grad()
+        out["loss"].backward()
+        opt.step()
+        losses.append(float(out["loss"]))
+    assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("semantics", ["literal", "intended"])
 def test_fullmodel_literal_loop_equals_collapsed(semantics):
     g = golden(f"fullmodel_{semantics}_tiny")
     model, images = _build_full("tiny", g, semantics, "bf16x3", collapse=False)
