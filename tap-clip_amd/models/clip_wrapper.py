@@ -180,6 +180,13 @@ class CLIPWrapper(nn.Module):
         self._vision = engine.VisionTower(self.cfg, state_dict, dev, precision)
         self._text = engine.TextTower(self.cfg, state_dict, dev, precision)
 
+        # a later load_state_dict (reference test_cross_domain.py:61 loads `clip.model.*` back with
+        # strict=False) must also reach the packed copies inside the HIP handles
+        self._reload_pending = False
+        self.weights_version = 0
+        self._register_load_state_dict_pre_hook(CLIPWrapper._note_incoming_weights, with_module=True)
+        self.register_load_state_dict_post_hook(CLIPWrapper._repack_after_load)
+
         self.attention_maps: List[torch.Tensor] = []
         self.tokenizer = HashTokenizer(self.cfg.vocab, self.cfg.ctx)
         self.preprocess = _make_preprocess(self.cfg.image_size)
@@ -196,6 +203,20 @@ class CLIPWrapper(nn.Module):
                     node.add_module(name, cls(self) if cls else _Bag())
                 node = node._modules[name]
             node.register_parameter(parts[-1], nn.Parameter(t.detach().to(dev, torch.float32), requires_grad=False))
+
+    @staticmethod
+    def _note_incoming_weights(module, state_dict, prefix, *args):
+        module._reload_pending = any(k.startswith(prefix + "model.") for k in state_dict)
+
+    @staticmethod
+    def _repack_after_load(module, incompatible_keys):
+        if module._reload_pending:
+            module._reload_pending = False
+            sd = {k: v.detach() for k, v in module.model.state_dict().items()}
+            dev = torch.device(module.device)
+            module._vision = engine.VisionTower(module.cfg, sd, dev, module.precision)
+            module._text = engine.TextTower(module.cfg, sd, dev, module.precision)
+            module.weights_version += 1
 
     # ---- reference surface -----------------------------------------------------------------
     def reset(self) -> None:

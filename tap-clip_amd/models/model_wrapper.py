@@ -85,6 +85,17 @@ class FullModel(nn.Module):
         self.logit_scale = nn.Parameter(torch.ones([]) * math.log(1 / 0.07))
         self.collapse_text = collapse_text
         self.gather_images = gather_images
+        # a checkpoint that carries other `clip.model.*` weights re-packs the towers (clip_wrapper.py here);
+        # the frozen class-token embeddings derived from them are then re-computed as well
+        self._clip_version = getattr(clip_wrapper, "weights_version", 0)
+        self.register_load_state_dict_post_hook(FullModel._refresh_after_load)
+
+    @staticmethod
+    def _refresh_after_load(module, incompatible_keys):
+        v = getattr(module.clip, "weights_version", 0)
+        if v != module._clip_version:
+            module._clip_version = v
+            module.prompt_learner.refresh_token_bank()
 
     # ---- text side -----------------------------------------------------------------------------
     def text_features(self) -> torch.Tensor:

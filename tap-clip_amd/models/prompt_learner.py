@@ -52,6 +52,14 @@ class PromptLearner(nn.Module):
         self.context_bank[class_name] = nn.Parameter(init)
         self._tok_cache = None
 
+    @torch.no_grad()
+    def refresh_token_bank(self) -> None:
+        """Re-embed every class prompt (after the CLIP weights were replaced by a load_state_dict)."""
+        for class_name in self.context_bank:
+            ids = self.tokenizer(f"a photo of a {class_name}").to(self.device)
+            self.token_bank[class_name] = self.token_embedding(ids.unsqueeze(0)).squeeze(0)
+        self._tok_cache = None
+
     # ---- stacked views for the fused path ----------------------------------------------------
     def stacked_context(self) -> torch.Tensor:
         """[n_cls, P, D] in class order (differentiable w.r.t. every context_bank entry)."""

@@ -1,0 +1,77 @@
+"""Accuracy / attribution metrics with the reference's function names and return values
+(reference utils/eval_metrics.py:6-96), counting on the device.
+
+The reference walks every sample in Python (`t.item()` per sample: one host sync each,
+eval_metrics.py:26-29,60-63); here predictions are compared and binned per batch with two
+`bincount`s and the totals are read back once at the end.  The model contract is unchanged:
+`model(images)['logits']` is a `[B, n_cls]` float tensor (eval_metrics.py:19-20)."""
+from collections import defaultdict
+
+import torch
+
+
+@torch.no_grad()
+def _count(model, dataloader, device):
+    model.eval()
+    correct = total = None
+    for images, labels in dataloader:
+        images, labels = images.to(device), labels.to(device)
+        logits = model(images)["logits"]
+        n_cls = logits.shape[1]
+        # under gather_images every rank holds the global logits; labels must then be global too
+        preds = torch.argmax(logits, dim=1)
+        hit = (preds == labels).to(torch.int64)
+        size = max(n_cls, int(labels.max()) + 1) if correct is None else max(n_cls, correct.numel(), int(labels.max()) + 1)
+        c = torch.bincount(labels, weights=hit.double(), minlength=size)
+        t = torch.bincount(labels, minlength=size).double()
+        if correct is None:
+            correct, total = c, t
+        else:
+            if size > correct.numel():
+                pad = size - correct.numel()
+                correct = torch.nn.functional.pad(correct, (0, pad))
+                total = torch.nn.functional.pad(total, (0, pad))
+            correct[: c.numel()] += c
+            total[: t.numel()] += t
+    if correct is None:
+        return torch.zeros(0), torch.zeros(0)
+    return correct.cpu(), total.cpu()
+
+
+def evaluate_accuracy(model, dataloader, device):
+    """Overall accuracy in percent; prints the per-class table like the reference."""
+    correct, total = _count(model, dataloader, device)
+    n = float(total.sum())
+    acc = 100.0 * float(correct.sum()) / n if n > 0 else 0.0
+    print(f"Overall Accuracy: {acc:.2f}%")
+    print("Per-Class Accuracy:")
+    for cls in range(total.numel()):
+        if total[cls] > 0:
+            print(f" - Class {cls:2d}: {100.0 * float(correct[cls]) / float(total[cls]):.2f}% ({int(correct[cls])}/{int(total[cls])})")
+    return acc
+
+
+def evaluate_per_class_accuracy(model, dataloader, device, class_names=None):
+    """{class name or index: accuracy %} for the classes that occur."""
+    correct, total = _count(model, dataloader, device)
+    out = {}
+    for cls in range(total.numel()):
+        if total[cls] > 0:
+            name = class_names[cls] if class_names else str(cls)
+            out[name] = 100.0 * float(correct[cls]) / float(total[cls])
+    return out
+
+
+def attribution_entropy(attribution_scores):
+    """Mean entropy of the attribution distributions (lower = more concentrated)."""
+    p = attribution_scores + 1e-8
+    return float((-(p * torch.log(p)).sum(dim=-1)).mean())
+
+
+def attribution_variance(attribution_scores, labels):
+    """Mean over label groups of the per-token variance of their attribution vectors."""
+    groups = defaultdict(list)
+    for a, l in zip(attribution_scores, labels):
+        groups[int(l)].append(a)
+    vs = [float(torch.stack(g).var(dim=0).mean()) for g in groups.values()]
+    return sum(vs) / len(vs) if vs else 0.0

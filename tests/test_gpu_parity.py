@@ -374,6 +374,59 @@ def test_fullmodel_vitb32_cfg1_vs_reference(semantics):
         torch.cuda.empty_cache()
 
 
+# ---- checkpoint round trip and the evaluation contract -------------
+def test_checkpoint_roundtrip_repacks_towers():
+    """`torch.save(model.state_dict())` (train.py:131-132) -> `load_state_dict(..., strict=False)` into a model
+    built from OTHER weights (test_cross_domain.py:43-61, incl. the legacy `context_emb` conversion) gives the
+    saved model's logits: the `clip.model.*` tensors must reach the packed HIP weights, not only the torch copies."""
+    from tap_clip_amd.models import CLIPWrapper, FullModel
+
+    cfg = configs.get_config("tiny")
+    names = ["Backpack", "Laptop", "Mug"]
+    images = synth.make_images(4, cfg, 0).to(DEV)
+
+    def build(seed):
+        torch.manual_seed(seed)
+        clip = CLIPWrapper("tiny", None, DEV, precision="bf16x3", state_dict=synth.make_state_dict(cfg, seed=seed))
+        return FullModel(names, clip, prompt_len=5, class_specific=True).eval()
+
+    a, b = build(2), build(3)
+    with torch.no_grad():
+        ref = a(images)["logits"]
+        assert rel_max(b(images)["logits"].cpu(), ref.cpu()) > 1e-2  # different weights, different answer
+    saved = {k: v.detach().cpu().clone() for k, v in a.state_dict().items()}
+    # the script's legacy path: context stored as one [n_cls, P, D] tensor
+    legacy = {k: v for k, v in saved.items() if "prompt_learner" not in k}
+    legacy["prompt_learner.context_emb"] = torch.stack([saved[f"prompt_learner.context_bank.{c}"] for c in names])
+    converted = {f"prompt_learner.context_bank.{c}": legacy["prompt_learner.context_emb"][i] for i, c in enumerate(names)}
+    converted.update({k: v for k, v in legacy.items() if "prompt_learner" not in k})
+    missing, unexpected = b.load_state_dict(converted, strict=False)
+    assert not unexpected
+    with torch.no_grad():
+        assert rel_max(b(images)["logits"].cpu(), ref.cpu()) < 1e-5
+    b.prompt_learner.add_class_prompt("Bike")  # unseen class at test time (test_cross_domain.py:65-67)
+    with torch.no_grad():
+        assert b(images)["logits"].shape == (4, 4)
+
+
+def test_eval_metrics_contract():
+    from tap_clip_amd.utils import eval_metrics
+
+    class Fixed(torch.nn.Module):
+        def forward(self, images, labels=None):
+            return {"logits": torch.nn.functional.one_hot(images[:, 0, 0, 0].long(), 3).float()}
+
+    x = torch.zeros(6, 1, 1, 1)
+    x[:, 0, 0, 0] = torch.tensor([0, 1, 2, 2, 1, 0])
+    y = torch.tensor([0, 1, 2, 0, 1, 1])
+    loader = [(x[:3], y[:3]), (x[3:], y[3:])]
+    assert abs(eval_metrics.evaluate_accuracy(Fixed(), loader, DEV) - 100.0 * 4 / 6) < 1e-9
+    per = eval_metrics.evaluate_per_class_accuracy(Fixed(), loader, DEV, ["a", "b", "c"])
+    assert per == {"a": 50.0, "b": pytest.approx(100.0 * 2 / 3), "c": 100.0}
+    p = torch.tensor([[0.5, 0.5], [1.0, 0.0]])
+    assert eval_metrics.attribution_entropy(p) == pytest.approx(0.5 * math.log(2), abs=1e-6)
+
+
 # ---- error behaviour ----------------------------------------------------------------------------
 def test_errors(eng):
     cfg = configs.get_config("tiny")
