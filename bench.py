@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--model", default="ViT-B-16")
     ap.add_argument("--classes", type=int, default=65)
     ap.add_argument("--prompt-len", type=int, default=16)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"],
+                    help="bf16 = the benchmarked fast path; bf16x3 = the split-bf16 parity mode (3 MFMA products)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-forward", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
@@ -95,7 +97,7 @@ def main():
 
     cfg = configs.get_config(args.model)
     sd = synth.make_state_dict(cfg, seed=2)
-    clip = CLIPWrapper(args.model, None, str(dev), precision="bf16", attn_semantics="intended", state_dict=sd)
+    clip = CLIPWrapper(args.model, None, str(dev), precision=args.precision, attn_semantics="intended", state_dict=sd)
     names = [f"class_{i}" for i in range(args.classes)]
     model = FullModel(names, clip, prompt_len=args.prompt_len, class_specific=True, gather_images=world > 1).eval()
     with torch.no_grad():  # seeded context (the reference draws torch.randn; any N(0,1) sample is the same workload)
@@ -145,7 +147,7 @@ def main():
     result = {
         "metric": "image_embeddings_per_sec", "value": round(value, 1), "unit": "img/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: {args.model} image encoder, synthetic {cfg.image_size}x{cfg.image_size}x3, "
                                f"batch {args.batch}/GPU, + all-gather of embeddings and {args.classes}-class logits",
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world, "tokens_per_image": cfg.n_tokens,

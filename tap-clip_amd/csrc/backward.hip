@@ -4,8 +4,8 @@
 // activations only (dX, never dW) -> the scaled context tokens.  The image tower needs no backward.
 //
 // GEMM dgrads re-use gemm*.hip with transposed packed weights; this file holds what is not a GEMM:
-//   attn_bwd_kernel      softmax-attention backward per (sequence, head), fp32 VALU out of LDS
-//                        (the text tower is 65 x 93 tokens: ~35 GFLOP per step, latency- not MFMA-bound)
+//   attn_bwd_kernel      softmax-attention backward per (sequence, head): fp32 operands in LDS, the five
+//                        products on the exact f32-input MFMA (the text tower is 65 x 93 tokens)
 //   ln_bwd_kernel        LayerNorm backward, fused with the residual-gradient accumulation
 //   pool_project_bwd     d(token pick -> @ text_projection -> L2 norm)   (model_wrapper.py:73-75)
 //   logits_bwd           d(scale * img . txt^T) w.r.t. txt and log-scale  (model_wrapper.py:79)
@@ -32,97 +32,144 @@ __device__ __forceinline__ void st_bf(bf16_t* hi, bf16_t* lo, int64_t i, float v
   }
 }
 
-// ---- attention backward.  One 256-thread workgroup per (sequence, head); T <= 128.
-// LDS: q, k, v, dO as fp32 [T][65] (65: conflict-free row and column walks) + P/dS [T][T+1] + delta[T].
+// ---- attention backward.  One 256-thread workgroup per (sequence, head); T <= 96 (the text tower's
+// prompt_len + 77).  Everything is fp32: operands sit in LDS as fp32 and the five products run on the exact
+// f32-input MFMA (v_mfma_f32_16x16x4_f32: A[row = l & 15][k = l >> 4], B[k = l >> 4][col = l & 15], one float
+// per lane per operand), so bf16 and bf16x3 towers share one kernel and the result is fp32-accurate.
+// LDS: q, k, v, dO as [Tp][65] (Tp = T rounded up to 16, pad rows zero; 65: conflict-free row and column
+// walks) + P/dS [Tp][Tp+1] + delta[Tp].
 //   S = q k^T (q carries the folded 1/sqrt(64)),  P = softmax(S),  dV = P^T dO,
 //   dP = dO v^T,  delta_i = sum_d dO_id O_id,  dS = P (dP - delta),  dq = dS k,  dk = dS^T q.
 constexpr int BWD_LD = 65;
 
+__device__ __forceinline__ f32x4_t mfma4(float a, float b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
   extern __shared__ float sh[];
   const int T = a.T, D = a.D;
+  const int Tp = (T + 15) & ~15, nt = Tp >> 4, LP = Tp + 1;
   float* q = sh;
-  float* k = q + T * BWD_LD;
-  float* v = k + T * BWD_LD;
-  float* dO = v + T * BWD_LD;
-  float* P = dO + T * BWD_LD;  // [T][T+1]
-  float* delta = P + T * (T + 1);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* k = q + Tp * BWD_LD;
+  float* v = k + Tp * BWD_LD;
+  float* dO = v + Tp * BWD_LD;
+  float* P = dO + Tp * BWD_LD;  // [Tp][Tp+1]
+  float* delta = P + Tp * LP;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
   const int seq = blockIdx.x / a.H, head = blockIdx.x - seq * a.H;
   const int64_t row0 = (int64_t)seq * T;
   const int64_t ld = 3 * (int64_t)D;
   const int qcol = head * 64, kcol = D + head * 64, vcol = 2 * D + head * 64;
 
-  for (int e = tid; e < T * 64; e += 256) {
+  for (int e = tid; e < Tp * 64; e += 256) {
     const int i = e >> 6, d = e & 63;
-    const int64_t g = (row0 + i) * ld + d;
-    q[i * BWD_LD + d] = ld_bf(a.qkv_hi, a.qkv_lo, g + qcol);
-    k[i * BWD_LD + d] = ld_bf(a.qkv_hi, a.qkv_lo, g + kcol);
-    v[i * BWD_LD + d] = ld_bf(a.qkv_hi, a.qkv_lo, g + vcol);
-    dO[i * BWD_LD + d] = ld_bf(a.dout_hi, a.dout_lo, (row0 + i) * D + head * 64 + d);
+    float fq = 0.f, fk = 0.f, fv = 0.f, fo = 0.f;
+    if (i < T) {
+      const int64_t g = (row0 + i) * ld + d;
+      fq = ld_bf(a.qkv_hi, a.qkv_lo, g + qcol);
+      fk = ld_bf(a.qkv_hi, a.qkv_lo, g + kcol);
+      fv = ld_bf(a.qkv_hi, a.qkv_lo, g + vcol);
+      fo = ld_bf(a.dout_hi, a.dout_lo, (row0 + i) * D + head * 64 + d);
+    }
+    q[i * BWD_LD + d] = fq;
+    k[i * BWD_LD + d] = fk;
+    v[i * BWD_LD + d] = fv;
+    dO[i * BWD_LD + d] = fo;
   }
   // delta_i = <dO_i, O_i>: one wave per row, O read straight from global
-  for (int i = wave; i < T; i += 4) {
-    const int64_t g = (row0 + i) * D + head * 64 + lane;
-    float s = ld_bf(a.dout_hi, a.dout_lo, g) * ld_bf(a.out_hi, a.out_lo, g);
+  for (int i = wave; i < Tp; i += 4) {
+    float s = 0.f;
+    if (i < T) {
+      const int64_t g = (row0 + i) * D + head * 64 + lane;
+      s = ld_bf(a.dout_hi, a.dout_lo, g) * ld_bf(a.out_hi, a.out_lo, g);
+    }
     s = wave_sum(s);
     if (lane == 0) delta[i] = s;
   }
   __syncthreads();
 
-  // S
-  for (int e = tid; e < T * T; e += 256) {
-    const int i = e / T, j = e - i * T;
-    float s = 0.f;
-#pragma unroll 16
-    for (int d = 0; d < 64; ++d) s = fmaf(q[i * BWD_LD + d], k[j * BWD_LD + d], s);
-    if (a.causal && j > i) s = -INFINITY;
-    P[i * (T + 1) + j] = s;
+  // S[i][j] = q_i . k_j   (tile (ti, tj): A = q rows, B = k rows, K = 64)
+  for (int tile = wave; tile < nt * nt; tile += 4) {
+    const int ti = tile / nt, tj = tile - ti * nt;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    const float* qa = q + (ti * 16 + lr) * BWD_LD + lq;
+    const float* kb = k + (tj * 16 + lr) * BWD_LD + lq;
+#pragma unroll
+    for (int d = 0; d < 64; d += 4) acc = mfma4(qa[d], kb[d], acc);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = ti * 16 + 4 * lq + e, j = tj * 16 + lr;
+      float sv = acc[e];
+      if (j >= T || (a.causal && j > i)) sv = -INFINITY;
+      P[i * LP + j] = sv;
+    }
   }
   __syncthreads();
-  // row softmax
-  for (int i = wave; i < T; i += 4) {
+  // row softmax (pad query rows see all-finite scores of zero vectors; their dO is zero, so they never count)
+  for (int i = wave; i < Tp; i += 4) {
     float mx = -INFINITY;
-    for (int j = lane; j < T; j += 64) mx = fmaxf(mx, P[i * (T + 1) + j]);
+    for (int j = lane; j < Tp; j += 64) mx = fmaxf(mx, P[i * LP + j]);
     mx = wave_max(mx);
     float sum = 0.f;
-    for (int j = lane; j < T; j += 64) {
-      const float p = expf(P[i * (T + 1) + j] - mx);
-      P[i * (T + 1) + j] = p;
+    for (int j = lane; j < Tp; j += 64) {
+      const float p = expf(P[i * LP + j] - mx);
+      P[i * LP + j] = p;
       sum += p;
     }
     sum = wave_sum(sum);
     const float inv = 1.0f / sum;
-    for (int j = lane; j < T; j += 64) P[i * (T + 1) + j] *= inv;
+    for (int j = lane; j < Tp; j += 64) P[i * LP + j] *= inv;
   }
   __syncthreads();
-  // dV[j][d] = sum_i P[i][j] dO[i][d]
-  for (int e = tid; e < T * 64; e += 256) {
-    const int j = e >> 6, d = e & 63;
-    float s = 0.f;
-    for (int i = 0; i < T; ++i) s = fmaf(P[i * (T + 1) + j], dO[i * BWD_LD + d], s);
-    st_bf(a.dqkv_hi, a.dqkv_lo, (row0 + j) * ld + vcol + d, s);
-  }
-  __syncthreads();
-  // dS in place
-  for (int e = tid; e < T * T; e += 256) {
-    const int i = e / T, j = e - i * T;
-    float s = 0.f;
-#pragma unroll 16
-    for (int d = 0; d < 64; ++d) s = fmaf(dO[i * BWD_LD + d], v[j * BWD_LD + d], s);
-    P[i * (T + 1) + j] *= (s - delta[i]);
-  }
-  __syncthreads();
-  // dq[i][d] = sum_j dS[i][j] k[j][d];  dk[j][d] = sum_i dS[i][j] q[i][d]
-  for (int e = tid; e < T * 64; e += 256) {
-    const int i = e >> 6, d = e & 63;
-    float sq = 0.f, sk = 0.f;
-    for (int j = 0; j < T; ++j) {
-      sq = fmaf(P[i * (T + 1) + j], k[j * BWD_LD + d], sq);
-      sk = fmaf(P[j * (T + 1) + i], q[j * BWD_LD + d], sk);
+  // dV[j][d] = sum_i P[i][j] dO[i][d]   (tile (tj, td): A[row j][k i] = P[i][j], B[k i][col d] = dO[i][d], K = Tp)
+  for (int tile = wave; tile < nt * 4; tile += 4) {
+    const int tj = tile >> 2, td = tile & 3;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (int i0 = 0; i0 < Tp; i0 += 4)
+      acc = mfma4(P[(i0 + lq) * LP + tj * 16 + lr], dO[(i0 + lq) * BWD_LD + td * 16 + lr], acc);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = tj * 16 + 4 * lq + e;
+      if (j < T) st_bf(a.dqkv_hi, a.dqkv_lo, (row0 + j) * ld + vcol + td * 16 + lr, acc[e]);
     }
-    st_bf(a.dqkv_hi, a.dqkv_lo, (row0 + i) * ld + qcol + d, sq);
-    st_bf(a.dqkv_hi, a.dqkv_lo, (row0 + i) * ld + kcol + d, sk);
+  }
+  __syncthreads();
+  // dS[i][j] = P[i][j] (dO_i . v_j - delta_i), in place
+  for (int tile = wave; tile < nt * nt; tile += 4) {
+    const int ti = tile / nt, tj = tile - ti * nt;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    const float* oa = dO + (ti * 16 + lr) * BWD_LD + lq;
+    const float* vb = v + (tj * 16 + lr) * BWD_LD + lq;
+#pragma unroll
+    for (int d = 0; d < 64; d += 4) acc = mfma4(oa[d], vb[d], acc);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = ti * 16 + 4 * lq + e, j = tj * 16 + lr;
+      P[i * LP + j] *= (acc[e] - delta[i]);
+    }
+  }
+  __syncthreads();
+  // dq[i][d] = sum_j dS[i][j] k[j][d];   dk[j][d] = sum_i dS[i][j] q[i][d]
+  for (int tile = wave; tile < nt * 4 * 2; tile += 4) {
+    const bool is_dk = tile >= nt * 4;
+    const int tl = is_dk ? tile - nt * 4 : tile;
+    const int tr = tl >> 2, td = tl & 3;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    if (!is_dk) {
+      for (int j0 = 0; j0 < Tp; j0 += 4)
+        acc = mfma4(P[(tr * 16 + lr) * LP + j0 + lq], k[(j0 + lq) * BWD_LD + td * 16 + lr], acc);
+    } else {
+      for (int i0 = 0; i0 < Tp; i0 += 4)
+        acc = mfma4(P[(i0 + lq) * LP + tr * 16 + lr], q[(i0 + lq) * BWD_LD + td * 16 + lr], acc);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int rr = tr * 16 + 4 * lq + e;
+      if (rr < T) st_bf(a.dqkv_hi, a.dqkv_lo, (row0 + rr) * ld + (is_dk ? kcol : qcol) + td * 16 + lr, acc[e]);
+    }
   }
 }
 
@@ -260,10 +307,13 @@ inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
 
-size_t attn_bwd_lds_bytes(int T) { return (size_t)(4 * T * BWD_LD + T * (T + 1) + T) * sizeof(float); }
+size_t attn_bwd_lds_bytes(int T) {
+  const int Tp = (T + 15) & ~15;
+  return (size_t)(4 * Tp * BWD_LD + Tp * (Tp + 1) + Tp) * sizeof(float);
+}
 
 hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s) {
-  if (a.T <= 0 || a.T > 128 || a.D != a.H * 64 || a.n_seq <= 0) return hipErrorInvalidValue;
+  if (a.T <= 0 || a.T > 96 || a.D != a.H * 64 || a.n_seq <= 0) return hipErrorInvalidValue;
   const size_t lds = attn_bwd_lds_bytes(a.T);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static size_t attr = 0;

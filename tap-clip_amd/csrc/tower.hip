@@ -600,7 +600,7 @@ int tapclip_text_backward(tapclip_tower_t* t, const float* x_in, const float* gr
   if (!t || !x_in || !grad_hidden || !grad_x || !workspace) return fail(TAPCLIP_EINVAL, "null argument");
   if (t->cfg.kind != TAPCLIP_TOWER_TEXT) return fail(TAPCLIP_EINVAL, "text_backward needs a text tower");
   if (n_seq <= 0 || tokens <= 0) return fail(TAPCLIP_EINVAL, "bad n_seq/tokens");
-  if (attn_bwd_lds_bytes(tokens) > 160 * 1024) return fail(TAPCLIP_EINVAL, "text_backward supports at most ~105 tokens per sequence (got %d)", tokens);
+  if (attn_bwd_lds_bytes(tokens) > 160 * 1024) return fail(TAPCLIP_EINVAL, "text_backward supports at most 96 tokens per sequence (got %d)", tokens);
   int rc = check_ready(t);
   if (rc) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
