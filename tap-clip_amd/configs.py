@@ -42,6 +42,7 @@ CONFIGS: Dict[str, ClipDims] = {
                                    TowerDims(512, 12, 8, 2048), quick_gelu=True),
     "ViT-B-16-quickgelu": ClipDims("ViT-B-16-quickgelu", 512, 224, 16, TowerDims(768, 12, 12, 3072),
                                    TowerDims(512, 12, 8, 2048), quick_gelu=True),
+    "ViT-L-14-336": ClipDims("ViT-L-14-336", 768, 336, 14, TowerDims(1024, 24, 16, 4096), TowerDims(768, 12, 12, 3072)),
     # small test model (kernel-legal dims: width % 128 == 0, head dim 64); not an open_clip model
     "tiny": ClipDims("tiny", 64, 32, 8, TowerDims(128, 2, 2, 256), TowerDims(128, 2, 2, 256), vocab=97, ctx=77),
 }

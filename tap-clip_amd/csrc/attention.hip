@@ -245,6 +245,226 @@ __global__ __launch_bounds__(512) void attn_kernel(AttnArgs a) {
   }
 }
 
+// ---- long sequences (T > 256, e.g. ViT-L/14@336: 577 tokens): the same transposed products, flash style.
+// Grid (sequence*head, query chunk); the workgroup walks the keys in blocks of KB*16, staging one K/V block
+// at a time in LDS; each wave owns QT 16-query tiles and keeps their running max m, partial row sum l
+// (lane-local: the rescale factor is row-uniform, so the 4 lanes of a query are reduced once at the end)
+// and O^T accumulators, rescaled by exp(m_old - m_new) whenever the block maximum grows.
+template <int KB, int QT, bool SPLIT>
+__global__ __launch_bounds__(512) void attn_flash_kernel(AttnArgs a) {
+  constexpr int KEYS = KB * 16;
+  constexpr int TILE = KEYS * 128;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* Kh = smem;
+  uint8_t* Vh = smem + TILE;
+  uint8_t* Kl = smem + 2 * TILE;
+  uint8_t* Vl = smem + 3 * TILE;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int T = a.T, D = a.D;
+  const int seq = blockIdx.x / a.H, head = blockIdx.x - seq * a.H;
+  const int64_t row0 = (int64_t)seq * T;
+  const int64_t ld = 3 * (int64_t)D;
+  const int qcol = head * 64, kcol = D + head * 64, vcol = 2 * D + head * 64;
+  const int n_qt = (T + 15) >> 4;
+  const int qt0 = (blockIdx.y * 8 + wave) * QT;
+  const float LOG2E = 1.44269504088896340736f;
+
+  bf16x8_t qh[QT][2], ql[SPLIT ? QT : 1][2];
+  float m[QT], l[QT];
+  f32x4_t oc[QT][4];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    int qc = (qt0 + t) * 16 + r;
+    if (qc >= T) qc = T - 1;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int64_t off = (row0 + qc) * ld + qcol + 32 * s + 8 * g;
+      qh[t][s] = *reinterpret_cast<const bf16x8_t*>(a.qkv_hi + off);
+      if (SPLIT) ql[t][s] = *reinterpret_cast<const bf16x8_t*>(a.qkv_lo + off);
+    }
+    m[t] = -INFINITY;
+    l[t] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oc[t][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int n_kb = (T + KEYS - 1) / KEYS;
+  const int qq = r >> 2, pp = r & 3;
+  for (int kb = 0; kb < n_kb; ++kb) {
+    const int key_base = kb * KEYS;
+    __syncthreads();  // every wave is done reading the previous block
+    constexpr int N_IT = KEYS * 8 / 512;
+#pragma unroll
+    for (int it = 0; it < N_IT; ++it) {
+      const int c = tid + 512 * it;
+      const int kk = c >> 3, kc = c & 7;
+      const int key = key_base + kk;
+      uint4 kv = make_uint4(0, 0, 0, 0), vv = kv, kvl = kv, vvl = kv;
+      if (key < T) {
+        const int64_t base = (row0 + key) * ld + kc * 8;
+        kv = *reinterpret_cast<const uint4*>(a.qkv_hi + base + kcol);
+        vv = *reinterpret_cast<const uint4*>(a.qkv_hi + base + vcol);
+        if (SPLIT) {
+          kvl = *reinterpret_cast<const uint4*>(a.qkv_lo + base + kcol);
+          vvl = *reinterpret_cast<const uint4*>(a.qkv_lo + base + vcol);
+        }
+      }
+      const int ko = kk * 128 + ((kc ^ (kk & 7)) << 4);
+      const int vo = kk * 128 + (((((kc >> 1) ^ (kk >> 1)) & 3) << 1 | (kc & 1)) << 4);
+      *reinterpret_cast<uint4*>(Kh + ko) = kv;
+      *reinterpret_cast<uint4*>(Vh + vo) = vv;
+      if (SPLIT) {
+        *reinterpret_cast<uint4*>(Kl + ko) = kvl;
+        *reinterpret_cast<uint4*>(Vl + vo) = vvl;
+      }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      if (qt0 + t >= n_qt) break;  // wave-uniform
+      const int qi = (qt0 + t) * 16 + r;
+      f32x4_t sc[KB];
+#pragma unroll
+      for (int kt = 0; kt < KB; ++kt) {
+        sc[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const int kk = kt * 16 + r;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int off = kk * 128 + (((4 * s + g) ^ (kk & 7)) << 4);
+          const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Kh + off);
+          sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qh[t][s], sc[kt], 0, 0, 0);
+          if (SPLIT) {
+            const bf16x8_t kfl = *reinterpret_cast<const bf16x8_t*>(Kl + off);
+            sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfl, qh[t][s], sc[kt], 0, 0, 0);
+            sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, ql[t][s], sc[kt], 0, 0, 0);
+          }
+        }
+      }
+      float bm = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < KB; ++kt) {
+        if ((key_base + kt * 16 + 15 >= T) || a.causal) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int key = key_base + kt * 16 + 4 * g + e;
+            if (key >= T || (a.causal && key > qi)) sc[kt][e] = -INFINITY;
+          }
+        }
+        bm = fmaxf(bm, fmaxf(fmaxf(sc[kt][0], sc[kt][1]), fmaxf(sc[kt][2], sc[kt][3])));
+      }
+      bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+      bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+      const float m_new = fmaxf(m[t], bm);
+      // m_new == -inf only while every key so far is masked (then p = 0 and nothing is accumulated)
+      const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f((m[t] - m_new) * LOG2E);
+      const float nmx = (m_new == -INFINITY) ? 0.0f : -m_new * LOG2E;
+      float bs = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KB; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(sc[kt][e], LOG2E, nmx));
+          sc[kt][e] = p;
+          bs += p;
+        }
+      l[t] = fmaf(l[t], alpha, bs);
+      m[t] = m_new;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) oc[t][dt][e] *= alpha;
+
+#pragma unroll
+      for (int s2 = 0; s2 < KB / 2; ++s2) {
+        bf16x8_t ph, pl;
+        {
+          bf16_t h[8], lo8[8];
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) {
+            const float p = sc[2 * s2 + (jj >> 2)][jj & 3];
+            if (SPLIT) split_bf(p, h[jj], lo8[jj]);
+            else h[jj] = f2bf(p);
+          }
+          s16x8_t hv = {(short)h[0], (short)h[1], (short)h[2], (short)h[3], (short)h[4], (short)h[5], (short)h[6], (short)h[7]};
+          ph = __builtin_bit_cast(bf16x8_t, hv);
+          if (SPLIT) {
+            s16x8_t lv = {(short)lo8[0], (short)lo8[1], (short)lo8[2], (short)lo8[3], (short)lo8[4], (short)lo8[5], (short)lo8[6], (short)lo8[7]};
+            pl = __builtin_bit_cast(bf16x8_t, lv);
+          }
+        }
+        const int key0 = 16 * (2 * s2) + 4 * g + qq;
+        const int key1 = 16 * (2 * s2 + 1) + 4 * g + qq;
+        const int sw = (key0 >> 1) & 3;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const int coff = ((dt ^ sw) << 5) + 8 * pp;
+          const bf16x8_t vf = tr_pair(Vh + key0 * 128 + coff, Vh + key1 * 128 + coff);
+          oc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, ph, oc[t][dt], 0, 0, 0);
+          if (SPLIT) {
+            const bf16x8_t vfl = tr_pair(Vl + key0 * 128 + coff, Vl + key1 * 128 + coff);
+            oc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfl, ph, oc[t][dt], 0, 0, 0);
+            oc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pl, oc[t][dt], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    if (qt0 + t >= n_qt) break;
+    const int qi = (qt0 + t) * 16 + r;
+    float sum = l[t];
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (qi < T) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int64_t off = (row0 + qi) * D + head * 64 + 16 * dt + 4 * g;
+        bf16_t h[4], lo4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (SPLIT) split_bf(oc[t][dt][e] * inv, h[e], lo4[e]);
+          else h[e] = f2bf(oc[t][dt][e] * inv);
+        }
+        uint2 phk;
+        phk.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+        phk.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+        *reinterpret_cast<uint2*>(a.out_hi + off) = phk;
+        if (SPLIT) {
+          uint2 plk;
+          plk.x = (uint32_t)lo4[0] | ((uint32_t)lo4[1] << 16);
+          plk.y = (uint32_t)lo4[2] | ((uint32_t)lo4[3] << 16);
+          *reinterpret_cast<uint2*>(a.out_lo + off) = plk;
+        }
+      }
+    }
+  }
+}
+
+template <bool SPLIT>
+hipError_t launch_flash(const AttnArgs& a, hipStream_t s) {
+  constexpr int KB = 8, QT = 2;
+  static bool attr_set = false;
+  const int smem_bytes = KB * 16 * 128 * (SPLIT ? 4 : 2);
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash_kernel<KB, QT, SPLIT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int n_qt = (a.T + 15) / 16;
+  const int chunks = (n_qt + 8 * QT - 1) / (8 * QT);
+  hipLaunchKernelGGL((attn_flash_kernel<KB, QT, SPLIT>), dim3((unsigned)(a.n_seq * a.H), (unsigned)chunks), dim3(512),
+                     smem_bytes, s, a);
+  return hipGetLastError();
+}
+
 template <int NKT, bool SPLIT>
 hipError_t launch_t(const AttnArgs& a, hipStream_t s) {
   static bool attr_set = false;
@@ -288,7 +508,11 @@ __global__ void head_mean_kernel(const float* __restrict__ probs, int H, int64_t
 }  // namespace
 
 hipError_t launch_attention(const AttnArgs& a, bool split, hipStream_t s) {
-  if (a.T <= 0 || a.T > 256 || a.D != a.H * 64 || a.n_seq <= 0) return hipErrorInvalidValue;
+  if (a.T <= 0 || a.D != a.H * 64 || a.n_seq <= 0) return hipErrorInvalidValue;
+  if (a.T > 256) {  // whole-head-in-LDS kernel holds at most 256 keys: flash-style kernel (no probability write-back)
+    if (a.probs != nullptr) return hipErrorInvalidValue;
+    return split ? launch_flash<true>(a, s) : launch_flash<false>(a, s);
+  }
   return split ? dispatch<true>(a, s) : dispatch<false>(a, s);
 }
 

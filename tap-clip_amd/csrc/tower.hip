@@ -395,10 +395,6 @@ int tapclip_tower_create(const tapclip_tower_cfg* cfg, tapclip_tower_t** out) {
     }
     const int G = cfg->image_size / cfg->patch;
     t->tokens_vision = G * G + 1;
-    if (t->tokens_vision > 256) {
-      delete t;
-      return fail(TAPCLIP_EINVAL, "%d tokens per image: the attention kernel holds at most 256 keys", t->tokens_vision);
-    }
     t->Kp = (3 * cfg->patch * cfg->patch + 63) / 64 * 64;
     for (const char* k : {"conv1.weight", "class_embedding", "positional_embedding", "ln_pre.weight", "ln_pre.bias",
                           "ln_post.weight", "ln_post.bias", "proj"})
@@ -573,7 +569,8 @@ int tapclip_text_forward(tapclip_tower_t* t, const float* x_in, int32_t n_seq, i
                          size_t workspace_bytes, tapclip_stream_t stream) {
   if (!t || !x_in || !workspace) return fail(TAPCLIP_EINVAL, "null argument");
   if (t->cfg.kind != TAPCLIP_TOWER_TEXT) return fail(TAPCLIP_EINVAL, "text_forward needs a text tower");
-  if (n_seq <= 0 || tokens <= 0 || tokens > 256) return fail(TAPCLIP_EINVAL, "bad n_seq/tokens (%d, %d); tokens <= 256", n_seq, tokens);
+  if (n_seq <= 0 || tokens <= 0) return fail(TAPCLIP_EINVAL, "bad n_seq/tokens (%d, %d)", n_seq, tokens);
+  if (tokens > 256 && (attn_heads || attn_mean)) return fail(TAPCLIP_EINVAL, "attention write-back needs tokens <= 256 (got %d)", tokens);
   int rc = check_ready(t);
   if (rc) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -138,6 +138,36 @@ def test_block_vs_golden(eng, tag, precision):
         assert rel_l2(r["hidden"].cpu(), y) < TOL_EMU
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("causal", [False, True])
+def test_long_sequence_flash_attention(eng, precision, causal):
+    """T = 577 (ViT-L/14@336 tokens) > 256 keys: the flash-style attention kernel, one block at d = 1024, H = 16."""
+    tower, sd = _one_layer_tower(eng, 1024, 16, 4096, 11, precision)
+    x = synth.normal([2, 577, 1024], 12, "flash.x")
+    r = tower.forward(x.to(DEV), causal=causal)
+    mask = clip_ref.causal_mask(577) if causal else None
+    y, _ = clip_ref.block_forward(x, sd, "transformer.resblocks.0.", 16, attn_mask=mask)
+    _report(f"flash block T=577 {precision} causal={causal}", r["hidden"], y)
+    assert rel_max(r["hidden"].cpu(), y) < (TOL if precision == "bf16x3" else TOL_BF16)
+    with pytest.raises(ValueError):
+        tower.forward(x.to(DEV), want_mean=True)  # write-back is only built for <= 256 tokens
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_encode_image_vit_l14_336_geometry(eng, precision):
+    """BASELINE configs[4] geometry (patch 14 -> K = 588 padded to 640, 577 tokens, width 1024, 16 heads,
+    embed 768) with 2 blocks instead of 24 so the CPU oracle stays quick."""
+    cfg = configs.ClipDims("L14-336-2blocks", 768, 336, 14, configs.TowerDims(1024, 2, 16, 4096), configs.TowerDims(768, 1, 12, 3072))
+    ocfg = clip_ref.ClipDims("L14-336-2blocks", 768, 336, 14, clip_ref.TowerDims(1024, 2, 16, 4096), clip_ref.TowerDims(768, 1, 12, 3072))
+    sd = synth.make_state_dict(cfg, seed=5, text=False)
+    images = synth.make_images(2, cfg, 6)
+    emb = eng.VisionTower(cfg, sd, DEV, precision).encode_image(images.to(DEV), normalize=True)
+    with torch.no_grad():
+        ref = clip_ref.encode_image(images, sd, ocfg, normalize=True)
+    _report(f"encode_image L/14@336 geometry {precision}", emb, ref)
+    assert rel_max(emb.cpu(), ref) < (TOL if precision == "bf16x3" else TOL_BF16)
+
+
 def test_causal_mask(eng):
     tower, sd = _one_layer_tower(eng, 512, 8, 2048, 7, "bf16x3")
     x = synth.normal([3, 77, 512], 9, "causal.x")
