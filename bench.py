@@ -148,7 +148,8 @@ def main():
         "metric": "image_embeddings_per_sec", "value": round(value, 1), "unit": "img/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: {args.model} image encoder, synthetic {cfg.image_size}x{cfg.image_size}x3, "
+        "config": {"workload": ("BASELINE configs[1]: " if (args.model, args.batch) == ("ViT-B-16", 256) else "") +
+                               f"{args.model} image encoder, synthetic {cfg.image_size}x{cfg.image_size}x3, "
                                f"batch {args.batch}/GPU, + all-gather of embeddings and {args.classes}-class logits",
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world, "tokens_per_image": cfg.n_tokens,
                    "classes": args.classes, "parallelism": f"dp{world}", "weights": "seeded random (no checkpoint offline)"},

@@ -16,6 +16,8 @@
 //        + (jj&3); the V^T fragment is read with the same key order)
 //     -> lane holds 4 consecutive d of one query: 8-byte stores.
 // bf16x3 (SPLIT): K, V, Q and P are hi/lo pairs and every product is three MFMAs.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -447,9 +449,9 @@ __global__ __launch_bounds__(512) void attn_flash_kernel(AttnArgs a) {
   }
 }
 
-template <bool SPLIT>
-hipError_t launch_flash(const AttnArgs& a, hipStream_t s) {
-  constexpr int KB = 8, QT = 2;
+template <bool SPLIT, int QT>
+hipError_t launch_flash_q(const AttnArgs& a, hipStream_t s) {
+  constexpr int KB = 8;
   static bool attr_set = false;
   const int smem_bytes = KB * 16 * 128 * (SPLIT ? 4 : 2);
   if (!attr_set) {
@@ -463,6 +465,20 @@ hipError_t launch_flash(const AttnArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((attn_flash_kernel<KB, QT, SPLIT>), dim3((unsigned)(a.n_seq * a.H), (unsigned)chunks), dim3(512),
                      smem_bytes, s, a);
   return hipGetLastError();
+}
+
+template <bool SPLIT>
+hipError_t launch_flash(const AttnArgs& a, hipStream_t s) {
+  // query tiles per wave: as few K/V re-stagings (query chunks of 8 * QT tiles) as the registers allow
+  static const int forced = [] {
+    const char* e = getenv("TAPCLIP_FLASH_QT");
+    return e ? atoi(e) : 0;
+  }();
+  const int n_qt = (a.T + 15) / 16;
+  // (5 tiles per wave would cover 577 tokens in one chunk but spills: 239 us vs 365 us at n = 64, T = 577)
+  const int qt = forced ? forced : (n_qt <= 16 ? 2 : 3);
+  if (qt == 2) return launch_flash_q<SPLIT, 2>(a, s);
+  return launch_flash_q<SPLIT, 3>(a, s);
 }
 
 template <int NKT, bool SPLIT>

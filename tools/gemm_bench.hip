@@ -116,6 +116,25 @@ int main(int argc, char** argv) {
     std::sort(t.begin(), t.end());
     printf("attention n%d T197 H12: median %8.1f us  min %8.1f us\n", a.n_seq, 1e3 * t[t.size() / 2], 1e3 * t[0]);
   }
+  {  // ViT-L/14@336 attention: 577 tokens, 16 heads (flash-style kernel)
+    AttnArgs a;
+    a.qkv_hi = A; a.qkv_lo = nullptr; a.out_hi = obf; a.out_lo = nullptr; a.probs = nullptr;
+    a.n_seq = 64; a.T = 577; a.H = 16; a.D = 1024; a.causal = 0;
+    std::vector<float> t;
+    for (int round = 0; round < iters; ++round) {
+      CK(launch_attention(a, false, s));
+      CK(hipEventRecord(e0, s));
+      for (int i = 0; i < 4; ++i) CK(launch_attention(a, false, s));
+      CK(hipEventRecord(e1, s));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      t.push_back(ms / 4);
+    }
+    std::sort(t.begin(), t.end());
+    const double fl = 4.0 * a.n_seq * a.H * 577.0 * 577.0 * 64.0;
+    printf("attention n%d T577 H16: median %8.1f us  %6.1f TFLOP/s\n", a.n_seq, 1e3 * t[t.size() / 2], fl / (t[t.size() / 2] * 1e-3) / 1e12);
+  }
   for (int k = 0; k < n_shapes; ++k) {
     std::sort(times[k].begin(), times[k].end());
     const double med = 1e3 * times[k][times[k].size() / 2], mn = 1e3 * times[k][0];
