@@ -188,7 +188,7 @@ def main():
             except Exception:
                 traffic = None
         result["roofline"] = {
-            "kernel": "gemm_kernel<EPI,false> (bf16 MFMA 16x16x32, 128x128x64 tile): QKV + out_proj + c_fc/GELU + c_proj launches",
+            "kernel": "gemm256_kernel<EPI,false,256,4> (persistent bf16 MFMA 16x16x32 GEMM, 256x256 tiles, 4-stage LDS-DMA ring): the QKV + out_proj + c_fc/GELU + c_proj launches",
             "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
             "traffic_note": "bytes/launch at the L2 fabric side (FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits included) from profiles/r01_pmc_traffic_bench.json; algorithmic operand+output bytes per launch average 313 MB",
@@ -197,7 +197,10 @@ def main():
         ln = prof.get("layernorm")
         if ln and ln[1]:
             rows = args.batch * cfg.n_tokens
-            ln_bytes = (cfg.vision.layers * 2) * rows * cfg.vision.width * (4 + 2) + rows * cfg.vision.width * 8
+            rd = rows * cfg.vision.width
+            # ln_pre (fp32 -> fp32), LN1 of block 0 (fp32 -> bf16), 2L-1 fused "x += branch; LN" (read x fp32 + branch
+            # bf16, write x fp32 + bf16 output)
+            ln_bytes = rd * 8 + rd * 6 + (2 * cfg.vision.layers - 1) * rd * (4 + 2 + 4 + 2)
             result["layernorm_hbm"] = {"achieved_GBps": round(ln_bytes * args.steps / (ln[0] * 1e-3) / 1e9, 1), "peak_GBps": HBM_PEAK_GBS,
                                        "bytes_per_step": ln_bytes}
         result["kernels"] = kern

@@ -72,7 +72,6 @@ __device__ __forceinline__ void lds_read_b128_x1(uint32_t a0, u32x4_t& v0) {
 }
 
 constexpr int BM = 256, BKS = 32;
-constexpr int GROUP_M = 8;
 constexpr int MAX_N_BIAS = 4096;  // bias vector kept in LDS
 
 template <int EPI, bool SPLIT, int BN, int NS>
@@ -125,12 +124,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
   const int KS1 = g.K / BKS;
   const int KS = SPLIT ? 3 * KS1 : KS1;
 
-  // tile id -> (m0, n0): grouped ordering, GROUP_M m-tiles x all n-tiles per group, m fastest
+  // tile id -> (m0, n0): grouped ordering, group_m (8) m-tiles x all n-tiles per group, m fastest
+  // (gemm_bench: 6..12 are within 2 % of each other, 2 and 32 lose 5-10 %)
   auto tile_origin = [&](int id, int64_t& m0, int& n0) {
-    const int per_group = GROUP_M * tiles_n;
+    const int GM = g.group_m;
+    const int per_group = GM * tiles_n;
     const int grp = id / per_group;
-    const int first_m = grp * GROUP_M;
-    const int gsize = tiles_m - first_m < GROUP_M ? tiles_m - first_m : GROUP_M;
+    const int first_m = grp * GM;
+    const int gsize = tiles_m - first_m < GM ? tiles_m - first_m : GM;
     const int in_grp = id - grp * per_group;
     m0 = (int64_t)(first_m + in_grp % gsize) * BM;
     n0 = (in_grp / gsize) * BN;
@@ -453,7 +454,13 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
     if (n_cu < 8) n_cu = 8;
   }
   const int64_t nwg = tiles < n_cu ? (tiles + 7) / 8 * 8 : n_cu;
-  hipLaunchKernelGGL((gemm256_kernel<EPI, SPLIT, BN, NS>), dim3((unsigned)nwg), dim3(512), smem_bytes, s, a);
+  GemmArgs b = a;
+  static const int gm_env = [] {
+    const char* e = getenv("TAPCLIP_GROUP_M");
+    return e ? atoi(e) : 0;
+  }();
+  if (gm_env > 0) b.group_m = gm_env;
+  hipLaunchKernelGGL((gemm256_kernel<EPI, SPLIT, BN, NS>), dim3((unsigned)nwg), dim3(512), smem_bytes, s, b);
   return hipGetLastError();
 }
 

@@ -34,6 +34,7 @@ struct GemmArgs {
   int32_t act;             // TAPCLIP_ACT_*
   const bf16_t* aux_hi = nullptr;  // EPI_GELU_BWD_BF16: upstream gradient dL/dh [M, N] (row stride ldo); may alias out
   const bf16_t* aux_lo = nullptr;
+  int32_t group_m = 8;             // m-tiles per group of the grouped tile order (gemm256.hip)
 };
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, bool split, hipStream_t s);
