@@ -113,6 +113,8 @@ class VisionTower(_Tower):
         x = _dev_f32(images, self.device)
         B = x.shape[0]
         out = torch.empty(B, self.cfg.embed_dim, dtype=torch.float32, device=self.device)
+        if B == 0:  # an empty batch encodes to an empty [0, E] tensor, as open_clip would
+            return out
         with torch.cuda.device(self.device):
             ws, nbytes = self.workspace(B, self.cfg.n_tokens)
             _lib.check(self.lib.tapclip_encode_image(self.handle, _ptr(x), B, _ptr(out), int(normalize), _ptr(ws),
@@ -239,6 +241,8 @@ def logits(img: torch.Tensor, txt: torch.Tensor, scale: float) -> torch.Tensor:
     B, E = i.shape
     Cn = t.shape[0]
     out = torch.empty(B, Cn, dtype=torch.float32, device=i.device)
+    if B == 0 or Cn == 0:
+        return out
     with torch.cuda.device(i.device):
         _lib.check(_lib.load().tapclip_logits(_ptr(i), _ptr(t), float(scale), B, Cn, E, _ptr(out), _stream_ptr(i.device)))
     return out

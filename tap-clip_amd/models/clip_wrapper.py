@@ -16,6 +16,7 @@ Extra keyword-only knobs (defaults keep behaviour):
                   nn.MultiheadAttention is the attention OUTPUT, so `.mean(dim=1)` gives [n,D]
                   (SURVEY.md section 0 item 1).
   state_dict      pass weights directly instead of `pretrained_path`.
+  bpe_path        CLIP's `bpe_simple_vocab_16e6.txt.gz` for the real tokenizer (default: hash stand-in).
 """
 from __future__ import annotations
 
@@ -159,7 +160,8 @@ def _make_preprocess(size: int) -> Callable:
 class CLIPWrapper(nn.Module):
     def __init__(self, model_name: str = "ViT-B-32", pretrained_path: Optional[str] = "path/to/open_clip_pytorch_model.bin",
                  device: str = "cuda", *, precision: str = "bf16", attn_semantics: str = "intended",
-                 state_dict: Optional[Dict[str, torch.Tensor]] = None, config: Optional[ClipDims] = None):
+                 state_dict: Optional[Dict[str, torch.Tensor]] = None, config: Optional[ClipDims] = None,
+                 bpe_path: Optional[str] = None):
         super().__init__()
         if attn_semantics not in ("intended", "literal"):
             raise ValueError(f"attn_semantics must be 'intended' or 'literal', got {attn_semantics!r}")
@@ -188,7 +190,11 @@ class CLIPWrapper(nn.Module):
         self.register_load_state_dict_post_hook(CLIPWrapper._repack_after_load)
 
         self.attention_maps: List[torch.Tensor] = []
-        self.tokenizer = HashTokenizer(self.cfg.vocab, self.cfg.ctx)
+        if bpe_path is not None:   # CLIP's real BPE vocabulary, when the user has the file
+            from ..tokenizer import BPETokenizer
+            self.tokenizer = BPETokenizer(bpe_path, self.cfg.ctx)
+        else:
+            self.tokenizer = HashTokenizer(self.cfg.vocab, self.cfg.ctx)
         self.preprocess = _make_preprocess(self.cfg.image_size)
         self.eval()
 

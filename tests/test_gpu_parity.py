@@ -217,6 +217,33 @@ def test_encode_image_real_dims_vs_golden(eng, name):
     # to the kernels than the fp32 one -- measured 2.0e-3 vs 2.2e-3 -- so it is only used per block above)
 
 
+@pytest.mark.parametrize("name,batch", [("ViT-B-32", 1), ("ViT-B-32", 11), ("ViT-B-32", 43), ("ViT-B-16", 3), ("ViT-B-16", 11), ("tiny", 300)])
+def test_encode_image_ragged_batches(eng, name, batch):
+    """Row counts that are not multiples of any tile (M = batch x tokens: 50, 550, 2150, 591, 2167, 5100) through
+    both GEMM kernels (register-staged below 2048 rows, persistent LDS-DMA above), parity mode vs the fp32 oracle."""
+    cfg = configs.get_config(name)
+    sd = synth.make_state_dict(cfg, seed=2, text=False)
+    images = synth.make_images(batch, cfg, 21)
+    emb = eng.VisionTower(cfg, sd, DEV, "bf16x3").encode_image(images.to(DEV)).cpu()
+    probe = [0, batch // 2, batch - 1] if batch > 3 else list(range(batch))
+    with torch.no_grad():
+        ref = clip_ref.encode_image(images[probe], sd, clip_ref.CONFIGS[name])
+    assert rel_max(emb[probe], ref) < TOL
+    assert torch.isfinite(emb).all()
+
+
+def test_empty_batch(eng):
+    from tap_clip_amd.models import CLIPWrapper, FullModel
+
+    cfg = configs.get_config("tiny")
+    sd = synth.make_state_dict(cfg, seed=2)
+    clip = CLIPWrapper("tiny", None, DEV, state_dict=sd)
+    assert clip.encode_image(torch.zeros(0, 3, 32, 32, device=DEV)).shape == (0, 64)
+    model = FullModel(["Mug", "Pen"], clip, prompt_len=5).eval()
+    with torch.no_grad():
+        assert model(torch.zeros(0, 3, 32, 32, device=DEV))["logits"].shape == (0, 2)
+
+
 def test_encode_image_full_batch_properties(eng, vitb16):
     """BASELINE.json configs[1] size (batch 256): size-independent properties -- unit norms,
     run-to-run determinism, and batch invariance (row i does not depend on its batch mates)."""

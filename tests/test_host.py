@@ -73,3 +73,48 @@ def test_all_gather_two_ranks_gloo(tmp_path):
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_image_folder_few_shot_loaders(tmp_path):
+    """reference dataset.py contract: relabelling in prompt order, num_shots per class, zero-shot -> no train loader"""
+    from PIL import Image
+
+    from tap_clip_amd.dataset import get_dataloaders
+
+    root = tmp_path / "Real_World"
+    for ci, cls in enumerate(["Alarm_Clock", "Backpack", "Mug", "Pen"]):
+        (root / cls).mkdir(parents=True)
+        for k in range(7):
+            Image.new("RGB", (40 + k, 30), (ci * 60, k * 30, 7)).save(root / cls / f"{k}.png")
+    pre = lambda img: torch.full((3, 4, 4), float(img.getpixel((0, 0))[0]))
+    names = ["Mug", "Alarm_Clock", "Pen"]  # prompt order != folder order; Backpack unused
+    train, val = get_dataloaders(str(root), names, batch_size=4, num_shots=2, preprocess=pre, num_workers=0, seed=0)
+    tr = [(x, y) for x, y in train]
+    assert sum(len(y) for _, y in tr) == 6
+    for x, y in tr + [(x, y) for x, y in val]:
+        assert x.shape[1:] == (3, 4, 4) and y.dtype == torch.int64
+        for xi, yi in zip(x, y):  # red channel encodes the folder: Mug=120 -> 0, Alarm_Clock=0 -> 1, Pen=180 -> 2
+            assert {120.0: 0, 0.0: 1, 180.0: 2}[float(xi[0, 0, 0])] == int(yi)
+    assert sum(len(y) for _, y in val) == 3 * 5
+    train0, val0 = get_dataloaders(str(root), names, batch_size=4, num_shots=0, preprocess=pre, num_workers=0, seed=0)
+    assert train0 is None and sum(len(y) for _, y in val0) == 3 * 7
+    with pytest.raises(KeyError):
+        get_dataloaders(str(root), ["Laptop"], num_workers=0)
+
+
+def test_bpe_tokenizer_algorithm(tmp_path):
+    """BPE merges applied by rank on a tiny hand-made vocabulary; SOT/EOT/padding/truncation layout."""
+    from tap_clip_amd.tokenizer import BPETokenizer
+
+    vocab = tmp_path / "bpe.txt"
+    vocab.write_text("#version: test\nm u\nmu g</w>\np h\nph o\nt o</w>\npho to</w>\n")
+    tok = BPETokenizer(str(vocab), context_length=8, n_merges=6)
+    enc = tok.encoder
+    ids = tok("A photo   of a MUG")
+    assert ids.shape == (1, 8) and ids[0, 0] == tok.sot
+    body = ids[0, 1:].tolist()
+    assert body[:2] == [enc["a</w>"], enc["photo</w>"]]
+    assert body[2:4] == [enc["o"], enc["f</w>"]]          # no merge for "of"
+    assert body[4:6] == [enc["a</w>"], enc["mug</w>"]] and body[6] == tok.eot
+    long = tok("mug " * 20)
+    assert long[0, -1] == tok.eot and long.shape == (1, 8)  # truncated, EOT kept
