@@ -110,19 +110,32 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
   // contiguous chunk of the grouped tile order; its gridDim/8 workgroups take ids j, j + bpx, ...
   const int tiles_m = (int)((g.M + BM - 1) / BM);
   const int tiles_n = g.N / BN;
-  const int total = tiles_m * tiles_n;
+  // (tiles >= g.split_from, if any, are not walked this way: they are K-split over the workgroups, below)
+  const int total = g.split_parts > 0 ? g.split_from : tiles_m * tiles_n;
   const int xcd = blockIdx.x & 7, bpx = gridDim.x >> 3;
   const int cq = total >> 3, crm = total & 7;
   const int chunk_lo = xcd * cq + (xcd < crm ? xcd : crm);
   const int chunk_hi = chunk_lo + cq + (xcd < crm ? 1 : 0);
+  // tail split: workgroup b < (tiles - split_from) * split_parts also computes part b % split_parts of
+  // tile split_from + b / split_parts, after its whole tiles
+  const int n_split_items = g.split_parts > 0 ? (tiles_m * tiles_n - g.split_from) * g.split_parts : 0;
+  const bool has_split = (int)blockIdx.x < n_split_items;
+  const int split_lid = has_split ? g.split_from + (int)blockIdx.x / g.split_parts : -1;
+  const int split_part = has_split ? (int)blockIdx.x % g.split_parts : 0;
   int lid = chunk_lo + (blockIdx.x >> 3);
-  if (lid >= chunk_hi) return;
+  bool cur_partial = false;
+  if (lid >= chunk_hi) {
+    if (!has_split) return;
+    lid = split_lid;
+    cur_partial = true;
+  }
 
   // bias -> LDS (zeros when absent); visible after the first barrier below
   for (int i = tid; i < g.N; i += 512) bias_lds[i] = g.bias ? g.bias[i] : 0.f;
 
   const int KS1 = g.K / BKS;
   const int KS = SPLIT ? 3 * KS1 : KS1;
+  const int KSP = g.split_parts > 0 ? KS / g.split_parts : KS;  // K steps of a split part
 
   // tile id -> (m0, n0): grouped ordering, group_m (8) m-tiles x all n-tiles per group, m fastest
   // (gemm_bench: 6..12 are within 2 % of each other, 2 and 32 lose 5-10 %)
@@ -174,8 +187,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
   const int w_base = A_BYTES + (wn * (BN / 4)) * 64 + frag_off;
 
   // ---- fetch cursor: the (tile, k-step) whose DMA is issued next; runs NS - 1 steps ahead of compute
-  int f_lid = lid, f_ks = 0;
-  bool f_valid = true;
+  int f_lid = lid, f_ks = cur_partial ? split_part * KSP : 0;
+  int f_ks_end = cur_partial ? f_ks + KSP : KS;
+  bool f_valid = true, f_partial = cur_partial;
   uint32_t a_off[AP], w_off[WP];
   {
     int64_t fm0;
@@ -185,10 +199,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
   }
   auto fetch_next = [&](int st) {  // issue the cursor's DMA into stage st, then advance the cursor
     stage_dma(st, f_ks, a_off, w_off);
-    if (++f_ks == KS) {
+    if (++f_ks == f_ks_end) {
       f_ks = 0;
+      f_ks_end = KS;
       f_lid += bpx;
-      f_valid = f_lid < chunk_hi;
+      f_valid = !f_partial && f_lid < chunk_hi;
+      if (!f_valid && !f_partial && has_split) {  // whole tiles done: the K-split part comes last
+        f_valid = f_partial = true;
+        f_lid = split_lid;
+        f_ks = split_part * KSP;
+        f_ks_end = f_ks + KSP;
+      }
       if (f_valid) {
         int64_t fm0;
         int fn0;
@@ -374,14 +395,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 
   for (;;) {
     tile_origin(lid, m0, n0);
-    const int next_lid = lid + bpx;
-    const bool has_next = next_lid < chunk_hi;
+    int next_lid = lid + bpx;
+    bool next_partial = false;
+    bool has_next = !cur_partial && next_lid < chunk_hi;
+    if (!has_next && !cur_partial && has_split) {
+      has_next = next_partial = true;
+      next_lid = split_lid;
+    }
+    const int ks_begin = cur_partial ? split_part * KSP : 0;
+    const int ks_end = cur_partial ? ks_begin + KSP : KS;
 
-    for (int ks = 0; ks < KS; ++ks) {
+    for (int ks = ks_begin; ks < ks_end; ++ks) {
       // ================= READ phase
-      if (ks == 0) {
+      if (ks == ks_begin) {
         if (pending) {
-          epilogue(em0, en0);
+          epilogue(em0, en0);  // (a pending tile is never a partial one: the K-split part is a workgroup's last item)
           // exactly NST stores were issued and the cursor is still issuing: the next NS-2 waits may skip them
           relaxed = (CLEAN_EPI && f_valid && (em0 + BM <= g.M)) ? NS - 2 : 0;
           pending = false;
@@ -391,7 +419,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
         for (int j = 0; j < NJ; ++j) {
           const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(bias_lds + n0 + wn * (BN / 4) + j * 16 + 4 * q);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) acc[j][i] = (EPI == EPI_PATCH_F32) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : bv;
+          for (int i = 0; i < 8; ++i) acc[j][i] = (EPI == EPI_PATCH_F32 || cur_partial) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : bv;
         }
       }
       // stage (st + NS - 1) % NS: its last readers (group B, one phase ago) passed the previous barrier
@@ -422,15 +450,55 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
     en0 = n0;
     if (!has_next) break;
     lid = next_lid;
+    cur_partial = next_partial;
   }
-  // the last tile's epilogue; group A is one phase ahead and owes the barrier group B started with
-  if (!grp_b) {
-    epilogue(em0, en0);
-    __builtin_amdgcn_s_barrier();
+  // the last item's epilogue; group A is one phase ahead and owes the barrier group B started with
+  if (cur_partial) {
+    // K-split part: raw fp32 accumulators (no bias, no activation) -> split_ws[slot][256][BN]
+    float* dst = g.split_ws + (size_t)((split_lid - g.split_from) * g.split_parts + split_part) * (BM * BN);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        *reinterpret_cast<f32x4_t*>(dst + (wm * 128 + i * 16 + r) * BN + wn * (BN / 4) + j * 16 + 4 * q) = acc[j][i];
   } else {
     epilogue(em0, en0);
   }
+  if (!grp_b) __builtin_amdgcn_s_barrier();
 }
+
+// ---- fix-up of the K-split tail tiles: out = epilogue(bias + sum of the parts)
+template <int EPI, int BN>
+__global__ __launch_bounds__(256) void splitk_fixup_kernel(GemmArgs g, int n_tiles) {
+  const int tiles_n = g.N / BN;
+  const int tiles_m = (int)((g.M + BM - 1) / BM);
+  constexpr int CHUNKS = BM * BN / 4 / 256;
+  const int t = blockIdx.x / CHUNKS;                     // tail tile index
+  const int e4 = (blockIdx.x % CHUNKS) * 256 + threadIdx.x;  // float4 index inside the tile
+  const int rr = e4 / (BN / 4), c4 = e4 % (BN / 4);
+  // tile id -> origin (same grouped order as the GEMM kernel)
+  const int id = g.split_from + t;
+  const int GM = g.group_m;
+  const int per_group = GM * tiles_n, grp = id / per_group, first_m = grp * GM;
+  const int gsize = tiles_m - first_m < GM ? tiles_m - first_m : GM;
+  const int in_grp = id - grp * per_group;
+  const int64_t m = (int64_t)(first_m + in_grp % gsize) * BM + rr;
+  const int n = (in_grp / gsize) * BN + c4 * 4;
+  if (t >= n_tiles || m >= g.M) return;
+  f32x4_t v = g.bias ? *reinterpret_cast<const f32x4_t*>(g.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < g.split_parts; ++p)
+    v += *reinterpret_cast<const f32x4_t*>(g.split_ws + (size_t)(t * g.split_parts + p) * (BM * BN) + rr * BN + c4 * 4);
+  if (EPI == EPI_BIAS_GELU_BF16) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = g.act == 0 ? gelu_erf_fast(v[e]) : gelu_quick(v[e]);
+  }
+  uint2 ph;
+  ph.x = pack_bf2(v[0], v[1]);
+  ph.y = pack_bf2(v[2], v[3]);
+  *reinterpret_cast<uint2*>(g.out_hi + m * g.ldo + n) = ph;
+}
+
+constexpr int SPLIT_WS_TILES = 256;  // at most one partial tile per workgroup
 
 template <int EPI, bool SPLIT, int BN>
 hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
@@ -460,7 +528,35 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
     return e ? atoi(e) : 0;
   }();
   if (gm_env > 0) b.group_m = gm_env;
+  // Tail split (bf16 outputs, 256-wide tiles): 591 tiles of an N = 768 GEMM are 2.31 rounds of 256 workgroups.
+  // The whole rounds run as whole tiles; each of the remaining R tiles is computed by S = floor(256 / R)
+  // workgroups over 1/S of K into fp32 partial tiles, summed by splitk_fixup_kernel.
+  b.split_parts = 0;
+  static const bool no_tail_split = getenv("TAPCLIP_NO_TAIL_SPLIT") != nullptr;
+  if (!SPLIT && BN == 256 && (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16) && a.split_ws != nullptr && !no_tail_split &&
+      tiles > n_cu) {
+    const int64_t full = tiles / n_cu, rem = tiles - full * n_cu;
+    const int ks = a.K / BKS;
+    if (rem > 0 && rem * 2 <= n_cu) {
+      int parts = (int)(n_cu / rem);
+      // a part shorter than ~16 K steps is all pipeline fill and drain: it costs more than the idle CUs
+      static const int min_ks = [] {
+        const char* e = getenv("TAPCLIP_TAIL_MIN_KS");
+        return e ? atoi(e) : 16;
+      }();
+      while (parts > 1 && (ks % parts != 0 || ks / parts < (min_ks > NS ? min_ks : NS))) --parts;
+      if (parts >= 2 && rem * parts <= SPLIT_WS_TILES) {
+        b.split_from = (int)(full * n_cu);
+        b.split_parts = parts;
+      }
+    }
+  }
   hipLaunchKernelGGL((gemm256_kernel<EPI, SPLIT, BN, NS>), dim3((unsigned)nwg), dim3(512), smem_bytes, s, b);
+  if (b.split_parts > 0) {
+    const int n_tail = (int)(tiles - b.split_from);
+    if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16)
+      hipLaunchKernelGGL((splitk_fixup_kernel<EPI, BN>), dim3((unsigned)(n_tail * (BM * BN / 4 / 256))), dim3(256), 0, s, b, n_tail);
+  }
   return hipGetLastError();
 }
 
@@ -485,6 +581,8 @@ hipError_t launch_e(const GemmArgs& a, bool split, hipStream_t s) {
 }
 
 }  // namespace
+
+size_t gemm256_split_ws_bytes() { return (size_t)SPLIT_WS_TILES * BM * 256 * sizeof(float); }
 
 bool gemm256_supports(const GemmArgs& a) {
   return a.N <= MAX_N_BIAS && a.K % BKS == 0 && a.K >= 4 * BKS && (a.M * a.lda * 2 < (int64_t)0xFFFF0000) &&

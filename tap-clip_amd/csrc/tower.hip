@@ -81,6 +81,7 @@ struct tapclip_tower {
         *lnpost_b = nullptr, *proj = nullptr;
   // text
   float *tok_emb = nullptr, *lnfin_g = nullptr, *lnfin_b = nullptr, *text_proj = nullptr;
+  float* split_ws = nullptr;  // scratch for the K-split tail tiles of gemm256.hip (64 MiB, handle-owned)
   // profiling
   bool prof_on = false;
   std::vector<ProfRec> prof;
@@ -212,6 +213,11 @@ int gemm(tapclip_tower* t, int slot, int epi, const bf16_t* a_hi, const bf16_t* 
          const bf16_t* aux_lo = nullptr) {
   GemmArgs g;
   g.aux_hi = aux_hi; g.aux_lo = aux_lo;
+  if (t->split_ws == nullptr && M >= 2048) {  // first large GEMM: allocate the tail-split scratch once
+    void* p = nullptr;
+    if (dev_alloc(t, gemm256_split_ws_bytes(), &p) == TAPCLIP_OK) t->split_ws = static_cast<float*>(p);
+  }
+  g.split_ws = t->split_ws;
   g.A_hi = a_hi; g.A_lo = a_lo; g.lda = lda;
   g.W_hi = w.hi; g.W_lo = w.lo;
   g.bias = bias;

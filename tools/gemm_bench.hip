@@ -64,6 +64,8 @@ int main(int argc, char** argv) {
   float* of32;
   CK(hipMalloc(&of32, (size_t)M * 768 * 4));
   CK(hipMemset(of32, 0, (size_t)M * 768 * 4));
+  float* split_ws;
+  CK(hipMalloc(&split_ws, gemm256_split_ws_bytes()));
   hipStream_t s;
   CK(hipStreamCreate(&s));
   hipEvent_t e0, e1;
@@ -80,6 +82,7 @@ int main(int argc, char** argv) {
     g.M = M; g.N = sh.N; g.K = sh.K;
     g.out_hi = obf; g.out_lo = nullptr; g.out_f32 = of32; g.ldo = sh.N;
     g.add_table = nullptr; g.rows_per_group = 0; g.act = 0;
+    g.split_ws = split_ws;
     const int epi = sh.epi % 100;
     for (int i = 0; i < reps; ++i) CK(launch_gemm(g, epi, false, s));
   };
