@@ -77,5 +77,9 @@ __device__ __forceinline__ float gelu_quick_grad(float x) {
   return s * (1.0f + 1.702f * x * (1.0f - s));
 }
 __device__ __forceinline__ float gelu_quick(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+// bf16 fast path: v_exp_f32 + v_rcp_f32 (1 ulp each) instead of the IEEE division sequence
+__device__ __forceinline__ float gelu_quick_fast(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
+}
 
 }  // namespace tapclip

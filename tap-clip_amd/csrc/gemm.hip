@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
           for (int e = 0; e < 4; ++e) v[e] = SPLIT ? gelu_erf(v[e]) : gelu_erf_fast(v[e]);
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_quick(v[e]);
+          for (int e = 0; e < 4; ++e) v[e] = SPLIT ? gelu_quick(v[e]) : gelu_quick_fast(v[e]);
         }
       }
       if (EPI == EPI_GELU_BWD_BF16) {

@@ -30,6 +30,7 @@
 //    16-byte fp32 stores).
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -89,9 +90,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
   // QKV output cost ~100 us of a 236 us launch (gemm_bench NOSTORE experiment, profiles/ r01).
   // (the GELU epilogue keeps the direct 8-byte fragment stores: its VALU work between them hides the store
   // issue cost, and the extra LDS round trip only adds to an already VALU-bound epilogue: 284 vs 314 us)
-  constexpr bool TR_EPI = !SPLIT && EPI == EPI_BIAS_BF16;
+#ifndef TAPCLIP_GELU_TR
+#define TAPCLIP_GELU_TR 0
+#endif
+  constexpr bool TR_EPI = !SPLIT && (EPI == EPI_BIAS_BF16 || (TAPCLIP_GELU_TR && EPI == EPI_BIAS_GELU_BF16));
   constexpr int ROW_CHUNKS = BN / 32;     // 16-B chunks per 16-row scratch row (wave covers BN/4 columns)
-  constexpr int NST = TR_EPI ? 8 * ROW_CHUNKS / 4 : NJ * 8;  // stores per wave of a clean epilogue
+  // The GELU epilogue stores straight from the accumulators, but with the W rows of each PAIR of 16-wide
+  // sub-tiles interleaved in groups of 4 (sub-tile 2J takes columns 32J + 8q' + 0..3, sub-tile 2J+1 columns
+  // 32J + 8q' + 4..7): a lane then holds 8 consecutive n of its row for the pair and stores 16 bytes, an
+  // instruction covers 16 rows x 64 B instead of 16 rows x 32 B, and there are half as many of them.
+  // Which W row feeds which MFMA output row is free: it is only the fragment's LDS read address.
+  constexpr bool PERM = !SPLIT && EPI == EPI_BIAS_GELU_BF16 && !TR_EPI;
+  constexpr int NST = TR_EPI ? 8 * ROW_CHUNKS / 4 : PERM ? NJ * 4 : NJ * 8;  // stores per wave of a clean epilogue
   constexpr int WAIT_STEADY = (NS - 2) * NDMA;
   constexpr int WAIT_RELAXED = WAIT_STEADY + NST;
   static_assert(WAIT_RELAXED <= 63, "vmcnt is a 6-bit field");
@@ -184,7 +194,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
   // fragment read offsets within a stage: row R = sub-tile base (multiple of 16) + r
   const int frag_off = r * 64 + ((q ^ (3 * ((r >> 3) & 1))) << 4);
   const int a_base = (wm * 128) * 64 + frag_off;
-  const int w_base = A_BYTES + (wn * (BN / 4)) * 64 + frag_off;
+  // PERM: lane r of sub-tile j reads W row 32 (j >> 1) + 8 (r >> 2) + 4 (j & 1) + (r & 3); bit 3 of that row
+  // is bit 2 of r, and the four 16-lane groups of the read still touch 16 distinct 16-B slots
+  const int w_frag_off = PERM ? (8 * (r >> 2) + (r & 3)) * 64 + ((q ^ (3 * ((r >> 2) & 1))) << 4) : frag_off;
+  const int w_base = A_BYTES + (wn * (BN / 4)) * 64 + w_frag_off;
+  auto w_sub_off = [](int j) { return PERM ? (j >> 1) * 2048 + (j & 1) * 256 : j * 1024; };  // bytes
+  // column (relative to n0 + wn * BN/4) of element e = 0 of this lane's accumulator acc[j][.]
+  auto col_of = [&](int j) { return PERM ? 32 * (j >> 1) + 8 * q + 4 * (j & 1) : j * 16 + 4 * q; };
 
   // ---- fetch cursor: the (tile, k-step) whose DMA is issued next; runs NS - 1 steps ahead of compute
   int f_lid = lid, f_ks = cur_partial ? split_part * KSP : 0;
@@ -285,6 +301,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
       // waited for with a COUNTED lgkmcnt (NJ writes + R reads of block i + 1 stay in flight) just before
       // its global stores, and block i + 1's GELU/pack VALU work runs under block i's LDS latency.
       constexpr int R = ROW_CHUNKS / 4;  // 16-B reads (= global stores) per lane per block
+      auto tr_body = [&](auto act_tag) {
+      constexpr int ACT = decltype(act_tag)::value;
       u32x4_t val[2][2];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -292,13 +310,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
         for (int j = 0; j < NJ; ++j) {
           f32x4_t v = acc[j][i];
           if (EPI == EPI_BIAS_GELU_BF16) {
-            if (g.act == 0) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);  // bf16 path: 2.5e-5 abs, see common.h
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = gelu_quick(v[e]);
-            }
+            for (int e = 0; e < 4; ++e) v[e] = ACT == 0 ? gelu_erf_fast(v[e]) : ACT == 1 ? gelu_quick_fast(v[e]) : v[e];
           }
           const unsigned long long pk = (unsigned long long)pack_bf2(v[0], v[1]) | ((unsigned long long)pack_bf2(v[2], v[3]) << 32);
           const int chunk = 2 * j + (q >> 1);
@@ -323,6 +336,42 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
         const int64_t m = mrow0 + 7 * 16 + rd_row[t];
         if (full || m < g.M) *reinterpret_cast<u32x4_t*>(g.out_hi + m * g.ldo + ncol0 + rd_col[t]) = val[1][t];
       }
+      };
+      if (EPI != EPI_BIAS_GELU_BF16 || g.act == 0) tr_body(std::integral_constant<int, 0>{});
+      else if (g.act == 1) tr_body(std::integral_constant<int, 1>{});
+      else tr_body(std::integral_constant<int, 2>{});
+      return;
+    }
+    if (PERM) {
+      // activation -> bf16, 8 consecutive n per lane and sub-tile pair; the activation kind is decided once
+      // per epilogue (wave-uniform), not per element
+      auto body = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int64_t m = m0 + wm * 128 + i * 16 + r;
+          if (m >= g.M) continue;
+          bf16_t* orow = g.out_hi + m * g.ldo + n0 + wn * (BN / 4) + 8 * q;
+#pragma unroll
+          for (int J = 0; J < NJ / 2; ++J) {
+            f32x4_t v0 = acc[2 * J][i], v1 = acc[2 * J + 1][i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v0[e] = ACT == 0 ? gelu_erf_fast(v0[e]) : ACT == 1 ? gelu_quick_fast(v0[e]) : v0[e];
+              v1[e] = ACT == 0 ? gelu_erf_fast(v1[e]) : ACT == 1 ? gelu_quick_fast(v1[e]) : v1[e];
+            }
+            u32x4_t pk;
+            pk[0] = pack_bf2(v0[0], v0[1]);
+            pk[1] = pack_bf2(v0[2], v0[3]);
+            pk[2] = pack_bf2(v1[0], v1[1]);
+            pk[3] = pack_bf2(v1[2], v1[3]);
+            *reinterpret_cast<u32x4_t*>(orow + 32 * J) = pk;
+          }
+        }
+      };
+      if (g.act == 0) body(std::integral_constant<int, 0>{});
+      else if (g.act == 1) body(std::integral_constant<int, 1>{});
+      else body(std::integral_constant<int, 2>{});  // 7 (tools/gemm_bench): no activation
       return;
     }
   // ---- epilogue: lane holds D[n = 4q + e][m = r] of each 16 x 16 tile (e = 0..3)
@@ -417,7 +466,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
         // accumulators start at the bias (lane holds n = n0 + wn * BN/4 + 16 j + 4 q + e for every m)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(bias_lds + n0 + wn * (BN / 4) + j * 16 + 4 * q);
+          const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(bias_lds + n0 + wn * (BN / 4) + col_of(j));
 #pragma unroll
           for (int i = 0; i < 8; ++i) acc[j][i] = (EPI == EPI_PATCH_F32 || cur_partial) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : bv;
         }
@@ -428,7 +477,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
       const uint8_t* base = smem + st * STAGE;
       bf16x8_t wf[NJ], af[8];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(base + w_base + j * 1024);
+      for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(base + w_base + w_sub_off(j));
 #pragma unroll
       for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(base + a_base + i * 1024);
       if (grp_b) wait_dma(issued);
@@ -460,7 +509,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
-        *reinterpret_cast<f32x4_t*>(dst + (wm * 128 + i * 16 + r) * BN + wn * (BN / 4) + j * 16 + 4 * q) = acc[j][i];
+        *reinterpret_cast<f32x4_t*>(dst + (wm * 128 + i * 16 + r) * BN + wn * (BN / 4) + col_of(j)) = acc[j][i];
   } else {
     epilogue(em0, en0);
   }

@@ -51,6 +51,9 @@ int main(int argc, char** argv) {
       {"out_proj N768  K768  bias->bf16 ", 768, 768, EPI_BIAS_BF16},
       {"fc_gelu  N3072 K768  gelu->bf16 ", 3072, 768, EPI_BIAS_GELU_BF16},
       {"proj     N768  K3072 bias->bf16 ", 768, 3072, EPI_BIAS_BF16},
+      {"fc_ident N3072 K768  noact->bf16", 3072, 768, EPI_BIAS_GELU_BF16 + 700},
+      {"fc_quick N3072 K768  quick->bf16", 3072, 768, EPI_BIAS_GELU_BF16 + 100},
+      {"fc_tr    N3072 K768  bias->bf16 ", 3072, 768, EPI_BIAS_BF16},
       {"qkv-like N2304 K3072 bias->bf16 ", 2304, 3072, EPI_BIAS_BF16},   // slope/intercept probe
       {"qkv-like N2304 K1536 bias->bf16 ", 2304, 1536, EPI_BIAS_BF16},
   };
@@ -81,7 +84,7 @@ int main(int argc, char** argv) {
     g.bias = bias;
     g.M = M; g.N = sh.N; g.K = sh.K;
     g.out_hi = obf; g.out_lo = nullptr; g.out_f32 = of32; g.ldo = sh.N;
-    g.add_table = nullptr; g.rows_per_group = 0; g.act = 0;
+    g.add_table = nullptr; g.rows_per_group = 0; g.act = sh.epi / 100;
     g.split_ws = split_ws;
     const int epi = sh.epi % 100;
     for (int i = 0; i < reps; ++i) CK(launch_gemm(g, epi, false, s));
