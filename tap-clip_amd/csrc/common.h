@@ -19,8 +19,12 @@ __device__ __forceinline__ bf16_t f2bf(float x) {
 __device__ __forceinline__ float bf2f(bf16_t b) {
   return __builtin_bit_cast(float, ((uint32_t)b) << 16);
 }
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// two fp32 -> packed bf16 pair, one v_cvt_pk_bf16_f32
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 // split x into hi + lo bf16 (lo = bf16(x - float(hi))): the bf16x3 operand form
 __device__ __forceinline__ void split_bf(float x, bf16_t& hi, bf16_t& lo) {

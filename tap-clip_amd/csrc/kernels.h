@@ -44,6 +44,26 @@ size_t gemm256_split_ws_bytes();
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, bool split, hipStream_t s);
 
+// ---- MX-fp8 GEMM (gemm_mx8.hip): e4m3 elements, one e8m0 scale (2^(s-127)) per 32 consecutive k.
+// Scale arrays are k-step major: scale of (row, 32-block b) at [(b >> 1) * rows_pad + row] * 2 + (b & 1).
+struct Mx8GemmArgs {
+  const uint8_t* A;        // [M, K] e4m3, row stride lda bytes (multiple of 16)
+  const uint8_t* A_scale;  // [K/64][m_pad][2]
+  int64_t lda, m_pad;      // m_pad: multiple of 8, >= M
+  const uint8_t* W;        // [N, K] e4m3, row stride K
+  const uint8_t* W_scale;  // [K/64][N][2]
+  const float* bias;       // [N] or nullptr
+  int64_t M;
+  int32_t N, K;
+  bf16_t* out_bf16;        // EPI_BIAS_BF16: [M, N] row stride ldo
+  int64_t ldo;
+  int32_t act = 0;
+  int32_t group_m = 8;
+  unsigned long long* stamps = nullptr;  // diagnostic build (-DMX8_STAMP) only
+};
+bool gemm_mx8_supports(const Mx8GemmArgs& a);
+hipError_t launch_gemm_mx8(const Mx8GemmArgs& a, int epilogue, hipStream_t s);
+
 // LayerNorm over rows; one wave per row.  out_hi/out_lo (bf16) or out_f32; x may alias out_f32.
 hipError_t launch_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta,
                             int64_t rows, int32_t d, bf16_t* out_hi, bf16_t* out_lo, float* out_f32,
