@@ -51,7 +51,12 @@ enum { TAPCLIP_ACT_GELU_ERF = 0, TAPCLIP_ACT_QUICK_GELU = 1 };
  *   BF16   : operands rounded to bf16, fp32 accumulate (fast path, benchmarked)
  *   BF16X3 : each operand split hi+lo bf16, 3 MFMA products (a_hi*b_hi + a_lo*b_hi
  *            + a_hi*b_lo), ~2^-16 relative: the parity mode vs the fp32 reference */
-enum { TAPCLIP_PREC_BF16 = 0, TAPCLIP_PREC_BF16X3 = 1 };
+enum {
+  TAPCLIP_PREC_BF16 = 0,   /* bf16 MFMA operands, fp32 accumulate (fast path)                         */
+  TAPCLIP_PREC_BF16X3 = 1, /* split-bf16 (hi + lo), three MFMA products: the 1e-3 parity mode         */
+  TAPCLIP_PREC_FP8 = 2     /* image tower only: block GEMMs on MXFP8 (OCP e4m3 + e8m0 scale per 32 k)
+                              MFMA, everything else as TAPCLIP_PREC_BF16 (BASELINE.json configs[4])   */
+};
 
 typedef struct tapclip_tower tapclip_tower_t; /* opaque */
 typedef void* tapclip_stream_t;               /* hipStream_t */
@@ -178,6 +183,21 @@ int tapclip_layernorm_f32(const float* x, const float* gamma, const float* beta,
 size_t tapclip_gemm_scratch_bytes(int64_t M, int32_t N, int32_t K);
 int tapclip_gemm_f32(const float* A, const float* W, const float* bias, int64_t M, int32_t N,
                      int32_t K, int32_t precision, float* C, void* scratch, size_t scratch_bytes,
+                     tapclip_stream_t stream);
+
+/* ---- MXFP8 unit entry points (the fp8 path's operand format, for its parity tests).
+ * Elements: OCP e4m3 (saturating at +-448, round to nearest even).  Scales: one e8m0 byte per 32
+ * consecutive k, value 2^(byte - 127) = 2^(floor(log2(block amax)) - 8), stored k-step major:
+ * scale of (row, block b) at scales[((b >> 1) * rows_pad + row) * 2 + (b & 1)].  K % 64 == 0. */
+int tapclip_mx8_quantize(const float* x, int64_t rows, int32_t K, uint8_t* q /* [rows, K] */,
+                         uint8_t* scales /* [K/64, rows_pad, 2] */, int64_t rows_pad,
+                         tapclip_stream_t stream);
+/* C = dequant(A) @ dequant(W)^T + bias on the MXFP8 MFMA path.  N % 256 == 0, K % 64 == 0, K >= 256,
+ * m_pad % 8 == 0.  epilogue 0: out_f32 [M, N] fp32.  epilogue 1: act(C) re-quantised to MXFP8 into
+ * out_q [M, N] / out_q_scale [N/64, m_pad, 2] (act = TAPCLIP_ACT_*; the c_fc epilogue of the fp8 path). */
+int tapclip_mx8_gemm(const uint8_t* a_q, const uint8_t* a_scale, int64_t M, int64_t m_pad,
+                     const uint8_t* w_q, const uint8_t* w_scale, const float* bias, int32_t N, int32_t K,
+                     int32_t epilogue, int32_t act, float* out_f32, uint8_t* out_q, uint8_t* out_q_scale,
                      tapclip_stream_t stream);
 
 /* ---- per-stage timing (HIP events on `stream`) for bench.py's roofline object.

@@ -41,6 +41,8 @@ SYMBOLS = [
     ("tapclip_layernorm_f32", _i32, [_p, _p, _p, _i64, _i32, _p, _p]),
     ("tapclip_gemm_scratch_bytes", _sz, [_i64, _i32, _i32]),
     ("tapclip_gemm_f32", _i32, [_p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _sz, _p]),
+    ("tapclip_mx8_quantize", _i32, [_p, _i64, _i32, _p, _p, _i64, _p]),
+    ("tapclip_mx8_gemm", _i32, [_p, _p, _i64, _i64, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
     ("tapclip_profile_enable", _i32, [_p, _i32]),
     ("tapclip_profile_read", _i32, [_p, C.POINTER(_f32), C.POINTER(_i64)]),
     ("tapclip_last_error", C.c_char_p, []),
@@ -49,8 +51,8 @@ SYMBOLS = [
 
 TOWER_VISION, TOWER_TEXT = 0, 1
 ACT_GELU_ERF, ACT_QUICK_GELU = 0, 1
-PREC_BF16, PREC_BF16X3 = 0, 1
-PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3}
+PREC_BF16, PREC_BF16X3, PREC_FP8 = 0, 1, 2
+PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp8": PREC_FP8}
 PROFILE_SLOTS = ("patch_embed", "layernorm", "gemm_qkv", "attention", "gemm_out_proj", "gemm_fc_gelu",
                  "gemm_proj", "pool_proj")
 

@@ -26,6 +26,27 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
   const f32x2_t v = {lo, hi};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+// ---- MXFP8 (OCP MX: e4m3 elements, one e8m0 scale per 32 consecutive k): quantisation helpers.
+// The shared exponent follows the OCP MX v1.0 recipe: 2^(floor(log2(amax)) - 8) (8 = e4m3's largest exponent),
+// elements saturate at +-448.  Scale arrays are k-step major (kernels.h Mx8GemmArgs).
+__device__ __forceinline__ uint32_t mx8_scale_byte(float amax) {  // amax >= 0
+  const int e = (int)(__float_as_uint(amax) >> 23) - 8;
+  return (uint32_t)(e < 0 ? 0 : e);  // zero / denormal blocks: 2^-127
+}
+__device__ __forceinline__ float mx8_inv_scale(uint32_t byte) { return __uint_as_float((254u - byte) << 23); }  // 2^(127 - byte)
+__device__ __forceinline__ uint32_t mx8_pack4(float a, float b, float c, float d, float inv) {
+  a = __builtin_amdgcn_fmed3f(a * inv, -448.f, 448.f);
+  b = __builtin_amdgcn_fmed3f(b * inv, -448.f, 448.f);
+  c = __builtin_amdgcn_fmed3f(c * inv, -448.f, 448.f);
+  d = __builtin_amdgcn_fmed3f(d * inv, -448.f, 448.f);
+  int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);  // bytes 0, 1 (round to nearest even, OCP e4m3 on gfx950)
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);       // bytes 2, 3
+  return (uint32_t)v;
+}
+__device__ __forceinline__ size_t mx8_scale_index(int64_t row, int block, int64_t rows_pad) {
+  return ((size_t)(block >> 1) * rows_pad + row) * 2 + (block & 1);
+}
+
 // split x into hi + lo bf16 (lo = bf16(x - float(hi))): the bf16x3 operand form
 __device__ __forceinline__ void split_bf(float x, bf16_t& hi, bf16_t& lo) {
   hi = f2bf(x);

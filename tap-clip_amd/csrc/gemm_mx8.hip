@@ -16,11 +16,14 @@
 //    16..31 to the second, and the scale VGPR of lane (r, h) is the scale of row r's block h.  Within a
 //    block the k order only has to agree between the two operands: both read 16 B at byte 16 h and 16 B at
 //    byte 32 + 16 h of the row.
-//  * LDS image: 64-B rows, 16-B chunk c of row R at slot c ^ ((R >> 3) & 3): the four 16-lane groups of a
+//  * LDS image: 64-B rows, 16-B chunk c of row R at slot c ^ ((R >> 2) & 3): the four 16-lane groups of a
 //    ds_read_b128 (rows {0-3,12-15,20-27} / {4-11,16-19,28-31} of a 32-row fragment, one chunk) then
-//    touch 16 distinct slots of the 256-B bank window.
+//    touch 16 distinct slots of the 256-B bank window -- for the natural row order of the A fragments and
+//    for both row permutations of the W fragments below.
 //  * swapped product (D = Wfrag . Afrag^T) and a free choice of which W row feeds which MFMA row: lane
-//    (m = l & 31, h) ends up with 16 CONSECUTIVE n (n = 16 h + reg) of each 32 x 32 tile.
+//    (m = l & 31, h) ends up with 16 CONSECUTIVE n of each 32 x 32 tile -- columns 32 jt + 16 h + reg of the
+//    wave's 64 for the bf16 / fp32 outputs, columns 32 h + 16 jt + reg for the MXFP8 output, where a lane
+//    then owns one whole 32-block of its row and the block maximum needs no cross-lane step.
 #include <cstdlib>
 #include <type_traits>
 
@@ -102,7 +105,9 @@ constexpr int MAX_N_BIAS = 4096;
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_mx8_kernel(Mx8GemmArgs g) {
   constexpr int NDMA = 5;                 // 2 A pieces + 2 W pieces + 1 scale piece per wave per stage
-  constexpr int NST = 16;                 // stores per wave of a clean epilogue (bf16: 8 tiles x 2)
+  // stores per wave of a clean epilogue: bf16 16 (8 tiles x 2 passes), MXFP8 8 data + 4 scale
+  constexpr int NST = EPI == EPI_BIAS_GELU_MX8 ? 12 : 16;
+  constexpr bool CLEAN_EPI = EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_MX8;
   constexpr int WAIT_STEADY = (NS - 2) * NDMA;
   constexpr int WAIT_RELAXED = WAIT_STEADY + NST;
   static_assert(WAIT_RELAXED <= 63, "vmcnt is a 6-bit field");
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(512) void gemm_mx8_kernel(Mx8GemmArgs g) {
     n0 = (in_grp / gsize) * BN;
   };
   // LDS-DMA sources.  Operand piece j of a stage = rows 16 j .. 16 j + 15 (1 KiB); wave w issues pieces w
-  // and w + 8; lane l covers row 16 j + (l >> 2), LDS chunk l & 3 <- source chunk (l & 3) ^ ((row >> 3) & 3).
+  // and w + 8; lane l covers row 16 j + (l >> 2), LDS chunk l & 3 <- source chunk (l & 3) ^ ((row >> 2) & 3).
   // Scale piece: the stage's 1 KiB = 64 chunks of 16 B (8 rows x 2 B): 0..31 A rows, 32..63 W rows; wave w
   // moves chunks 8 w .. 8 w + 7 with its lanes 0..7.
   auto tile_offsets = [&](int64_t m0, int n0, uint32_t (&a_off)[2], uint32_t (&w_off)[2], uint32_t& s_off, const uint8_t*& s_base,
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(512) void gemm_mx8_kernel(Mx8GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = 16 * (wave + 8 * i) + (lane >> 2);
-      const int sc = (lane & 3) ^ ((row >> 3) & 3);
+      const int sc = (lane & 3) ^ ((row >> 2) & 3);
       int64_t m = m0 + row;
       if (m >= g.M) m = g.M - 1;  // rows past M are computed but never stored
       a_off[i] = (uint32_t)(m * g.lda + sc * 16);
@@ -183,14 +188,16 @@ __global__ __launch_bounds__(512) void gemm_mx8_kernel(Mx8GemmArgs g) {
   };
 
   // fragment read offsets.  A fragment i: rows wm*128 + 32 i + r.  W fragment jt: MFMA row index r is fed by
-  // tile row nrow(r) = 16 ((r >> 2) & 1) + 4 (r >> 3) + (r & 3), so that D row (reg & 3) + 8 (reg >> 2) + 4 h
-  // is column 16 h + reg.
+  // tile row nrow(r) (+ JT_ROWS * jt), so that D row (reg & 3) + 8 (reg >> 2) + 4 h is column 16 h + reg of
+  // tile jt (bf16 / fp32 outputs: JT_ROWS = 32) or column 32 h + 16 jt + reg (MXFP8 output: JT_ROWS = 16).
+  constexpr bool QOUT = EPI == EPI_BIAS_GELU_MX8;
+  constexpr int JT_ROWS = QOUT ? 16 : 32;
   const int arow = wm * 128 + r;
-  const int nrow = 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
+  const int nrow = (QOUT ? 32 : 16) * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
   const int wrow = wn * 64 + nrow;
-  // bits 3, 4 of the row: 32 i, 32 jt and the wave bases are multiples of 32 and do not touch them
-  const int a_c0 = (h ^ ((arow >> 3) & 3)) << 4, a_c1 = ((2 + h) ^ ((arow >> 3) & 3)) << 4;
-  const int w_c0 = (h ^ ((wrow >> 3) & 3)) << 4, w_c1 = ((2 + h) ^ ((wrow >> 3) & 3)) << 4;
+  // bits 2, 3 of the row: 32 i, JT_ROWS jt and the wave bases are multiples of 16 and do not touch them
+  const int a_c0 = (h ^ ((arow >> 2) & 3)) << 4, a_c1 = ((2 + h) ^ ((arow >> 2) & 3)) << 4;
+  const int w_c0 = (h ^ ((wrow >> 2) & 3)) << 4, w_c1 = ((2 + h) ^ ((wrow >> 2) & 3)) << 4;
   const int a_base = arow * 64;
   const int w_base = A_BYTES + wrow * 64;
   const int as_base = A_BYTES + W_BYTES + arow * 2 + h;
@@ -279,8 +286,80 @@ __global__ __launch_bounds__(512) void gemm_mx8_kernel(Mx8GemmArgs g) {
     // reads 16 B back in row order and stores it, so a store instruction covers 16 rows x 64 B.  A wave's
     // LDS instructions execute in order: no barrier; the read of pass k is waited for (counted) after the
     // writes and the read of pass k + 1 have been issued.
+    if (EPI == EPI_BIAS_F32) {  // unit API: plain stores, lane holds columns 32 jt + 16 h + 0..15 of row m
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + wm * 128 + 32 * i + r;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+          float* dst = g.out_f32 + m * g.ldo + n0 + wn * 64 + 32 * jt + 16 * h;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            *reinterpret_cast<f32x4_t*>(dst + 4 * e) = f32x4_t{acc[jt][i][4 * e], acc[jt][i][4 * e + 1], acc[jt][i][4 * e + 2], acc[jt][i][4 * e + 3]};
+        }
+      }
+      return;
+    }
     const uint32_t sbase = lds_addr(scratch);
     const int row16 = r & 15;
+    if (EPI == EPI_BIAS_GELU_MX8) {
+      // lane (m = r, h) holds the 32-block h of its row: activation, block maximum, e8m0 scale and e4m3
+      // elements all in-lane.  32 rows x 64 B leave in two passes of 16 rows through the wave's LDS block
+      // (as below); the scale bytes of a 32-row block are 64 contiguous bytes (k-step major scale layout).
+      auto body = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+        const uint32_t wq0 = sbase + row16 * 64 + (((2 * h) ^ ((row16 >> 1) & 3)) << 4);
+        const uint32_t wq1 = sbase + row16 * 64 + (((2 * h + 1) ^ ((row16 >> 1) & 3)) << 4);
+        const int rr = lane >> 2, rc = lane & 3;
+        const uint32_t rd = sbase + rr * 64 + ((rc ^ ((rr >> 1) & 3)) << 4);
+        const bool full = m0 + BM <= g.M;
+        const int64_t mrow = m0 + wm * 128 + rr;
+        uint8_t* optr = g.out_q + mrow * g.ldo + n0 + wn * 64 + 16 * rc;
+        const int64_t step16 = 16 * g.ldo;
+        uint8_t* sptr = g.out_q_scale + ((size_t)((n0 >> 6) + wn) * g.out_m_pad + (m0 + wm * 128 + r)) * 2 + h;
+        u32x4_t val[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float y[32];
+          float amax = 0.f;
+#pragma unroll
+          for (int e = 0; e < 32; ++e) {
+            const float x = acc[e >> 4][i][e & 15];
+            y[e] = ACT == 0 ? gelu_erf_fast(x) : ACT == 1 ? gelu_quick_fast(x) : x;
+            amax = fmaxf(amax, fabsf(y[e]));
+          }
+          const uint32_t byte = mx8_scale_byte(amax);
+          const float inv = mx8_inv_scale(byte);
+          u32x4_t p0, p1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            p0[e] = mx8_pack4(y[4 * e], y[4 * e + 1], y[4 * e + 2], y[4 * e + 3], inv);
+            p1[e] = mx8_pack4(y[16 + 4 * e], y[16 + 4 * e + 1], y[16 + 4 * e + 2], y[16 + 4 * e + 3], inv);
+          }
+          if (full || m0 + wm * 128 + 32 * i + r < g.M) sptr[64 * i] = (uint8_t)byte;
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const int k = 2 * i + p;
+            if ((r >> 4) == p) {
+              lds_write_b128(wq0, p0);
+              lds_write_b128(wq1, p1);
+            }
+            lds_read_b128_nowait(rd, val[k & 1]);
+            if (k > 0) {
+              lds_wait_x1<3>(val[(k - 1) & 1]);
+              if (full || mrow + 16 * (k - 1) < g.M) *reinterpret_cast<u32x4_t*>(optr + (k - 1) * step16) = val[(k - 1) & 1];
+            }
+          }
+        }
+        lds_wait_x1<0>(val[1]);
+        if (full || mrow + 112 < g.M) *reinterpret_cast<u32x4_t*>(optr + 7 * step16) = val[1];
+      };
+      if (g.act == 0) body(std::integral_constant<int, 0>{});
+      else if (g.act == 1) body(std::integral_constant<int, 1>{});
+      else body(std::integral_constant<int, 2>{});
+      return;
+    }
     const uint32_t wr0 = sbase + row16 * 64 + (((2 * h) ^ ((row16 >> 1) & 3)) << 4);
     const uint32_t wr1 = sbase + row16 * 64 + (((2 * h + 1) ^ ((row16 >> 1) & 3)) << 4);
     const int rr = lane >> 2, rc = lane & 3;
@@ -333,12 +412,12 @@ __global__ __launch_bounds__(512) void gemm_mx8_kernel(Mx8GemmArgs g) {
       if (ks == 0) {
         if (pending) {
           epilogue(em0, en0);
-          relaxed = (em0 + BM <= g.M) ? NS - 2 : 0;
+          relaxed = (CLEAN_EPI && em0 + BM <= g.M) ? NS - 2 : 0;
           pending = false;
         }
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
-          const float* bp = bias_lds + n0 + wn * 64 + 32 * jt + 16 * h;
+          const float* bp = bias_lds + n0 + wn * 64 + (QOUT ? 32 * h + 16 * jt : 32 * jt + 16 * h);
           f32x16_t bv;
 #pragma unroll
           for (int e = 0; e < 16; ++e) bv[e] = bp[e];
@@ -351,9 +430,9 @@ __global__ __launch_bounds__(512) void gemm_mx8_kernel(Mx8GemmArgs g) {
       int wsc[2], asc[4];
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt) {
-        wf[jt][0] = *reinterpret_cast<const u32x4_t*>(base + w_base + jt * 2048 + w_c0);
-        wf[jt][1] = *reinterpret_cast<const u32x4_t*>(base + w_base + jt * 2048 + w_c1);
-        wsc[jt] = base[ws_base + jt * 64];
+        wf[jt][0] = *reinterpret_cast<const u32x4_t*>(base + w_base + jt * (JT_ROWS * 64) + w_c0);
+        wf[jt][1] = *reinterpret_cast<const u32x4_t*>(base + w_base + jt * (JT_ROWS * 64) + w_c1);
+        wsc[jt] = base[ws_base + jt * (JT_ROWS * 2)];
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -414,25 +493,17 @@ __global__ __launch_bounds__(512) void gemm_mx8_kernel(Mx8GemmArgs g) {
 #endif
 }
 
-}  // namespace
-
-bool gemm_mx8_supports(const Mx8GemmArgs& a) {
-  return a.N % BN == 0 && a.K % BK == 0 && a.K >= BK * NS && a.N <= MAX_N_BIAS && a.lda % 16 == 0 && a.m_pad % 8 == 0 &&
-         a.m_pad >= 8 && (uint64_t)a.M * (uint64_t)a.lda < (1ull << 32) && (uint64_t)a.N * (uint64_t)a.K < (1ull << 32) &&
-         (uint64_t)a.m_pad * 2 < (1ull << 32);
-}
-
-hipError_t launch_gemm_mx8(const Mx8GemmArgs& a, int epilogue, hipStream_t s) {
-  if (!gemm_mx8_supports(a) || epilogue != EPI_BIAS_BF16) return hipErrorInvalidValue;
-  #ifdef MX8_STAMP
+template <int EPI>
+hipError_t launch_mx8_t(const Mx8GemmArgs& a, hipStream_t s) {
+#ifdef MX8_STAMP
   const int smem_bytes = NS * STAGE + 8 * 1024 + MAX_N_BIAS * 4 + 4096;
 #else
   const int smem_bytes = NS * STAGE + 8 * 1024 + a.N * 4;
 #endif
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_mx8_kernel<EPI_BIAS_BF16>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, NS * STAGE + 8 * 1024 + MAX_N_BIAS * 4 + 4096);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_mx8_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       NS * STAGE + 8 * 1024 + MAX_N_BIAS * 4 + 4096);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
@@ -446,8 +517,33 @@ hipError_t launch_gemm_mx8(const Mx8GemmArgs& a, int epilogue, hipStream_t s) {
   }
   const int64_t tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
   const int64_t nwg = tiles < n_cu ? (tiles + 7) / 8 * 8 : n_cu;
-  hipLaunchKernelGGL((gemm_mx8_kernel<EPI_BIAS_BF16>), dim3((unsigned)nwg), dim3(512), smem_bytes, s, a);
+  hipLaunchKernelGGL((gemm_mx8_kernel<EPI>), dim3((unsigned)nwg), dim3(512), smem_bytes, s, a);
   return hipGetLastError();
+}
+
+}  // namespace
+
+bool gemm_mx8_supports(const Mx8GemmArgs& a) {
+  return a.M > 0 && a.N % BN == 0 && a.K % BK == 0 && a.K >= BK * NS && a.N <= MAX_N_BIAS && a.lda % 16 == 0 && a.m_pad % 8 == 0 &&
+         a.m_pad >= 8 && (uint64_t)a.M * (uint64_t)a.lda < (1ull << 32) && (uint64_t)a.N * (uint64_t)a.K < (1ull << 32) &&
+         (uint64_t)a.m_pad * 2 < (1ull << 32);
+}
+
+hipError_t launch_gemm_mx8(const Mx8GemmArgs& a, int epilogue, hipStream_t s) {
+  if (!gemm_mx8_supports(a)) return hipErrorInvalidValue;
+  switch (epilogue) {
+    case EPI_BIAS_BF16:
+      if (a.out_bf16 == nullptr || a.ldo % 8 != 0) return hipErrorInvalidValue;
+      return launch_mx8_t<EPI_BIAS_BF16>(a, s);
+    case EPI_BIAS_F32:
+      if (a.out_f32 == nullptr || a.ldo % 4 != 0) return hipErrorInvalidValue;
+      return launch_mx8_t<EPI_BIAS_F32>(a, s);
+    case EPI_BIAS_GELU_MX8:
+      if (a.out_q == nullptr || a.out_q_scale == nullptr || a.ldo % 16 != 0 || a.out_m_pad < a.M) return hipErrorInvalidValue;
+      return launch_mx8_t<EPI_BIAS_GELU_MX8>(a, s);
+    default:
+      return hipErrorInvalidValue;
+  }
 }
 
 }  // namespace tapclip

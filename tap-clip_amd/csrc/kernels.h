@@ -14,6 +14,7 @@ enum Epilogue {
   EPI_PATCH_F32 = 3,       // out_f32[b*(G2+1)+1+p, n] = acc + add_table[(1+p), n]        (patch embed, K1)
   EPI_BIAS_F32 = 4,        // out_f32[m,n] = acc + bias[n]   (unit API / literal hook attn_out)
   EPI_GELU_BWD_BF16 = 5,   // out_hi(/lo)[m,n] = bf16(act'(acc + bias[n]) * aux[m,n])   (backward of c_fc's GELU)
+  EPI_BIAS_GELU_MX8 = 6,   // gemm_mx8.hip only: out_q/out_q_scale = MXFP8(act(acc + bias[n]))          (c_fc of the fp8 path)
 };
 
 struct GemmArgs {
@@ -55,12 +56,19 @@ struct Mx8GemmArgs {
   const float* bias;       // [N] or nullptr
   int64_t M;
   int32_t N, K;
-  bf16_t* out_bf16;        // EPI_BIAS_BF16: [M, N] row stride ldo
+  bf16_t* out_bf16 = nullptr;  // EPI_BIAS_BF16: [M, N] row stride ldo
+  float* out_f32 = nullptr;    // EPI_BIAS_F32 (unit API)
+  uint8_t* out_q = nullptr;        // EPI_BIAS_GELU_MX8: e4m3 [M, N], row stride ldo bytes
+  uint8_t* out_q_scale = nullptr;  //   its scales [N/64][out_m_pad][2]
+  int64_t out_m_pad = 0;
   int64_t ldo;
   int32_t act = 0;
   int32_t group_m = 8;
   unsigned long long* stamps = nullptr;  // diagnostic build (-DMX8_STAMP) only
 };
+// fp32 [rows, K] (row stride ldx; the first scale_rows rows multiplied by scale) -> e4m3 [rows, ldq] + scales [K/64][rows_pad][2]
+hipError_t launch_quantize_mx8(const float* x, int64_t rows, int32_t K, int64_t ldx, int64_t scale_rows, float scale, uint8_t* q,
+                               int64_t ldq, uint8_t* sc, int64_t rows_pad, hipStream_t s);
 bool gemm_mx8_supports(const Mx8GemmArgs& a);
 hipError_t launch_gemm_mx8(const Mx8GemmArgs& a, int epilogue, hipStream_t s);
 

@@ -1,0 +1,53 @@
+// MXFP8 operand preparation for gemm_mx8.hip: fp32 rows -> e4m3 elements + e8m0 block scales.
+// Used at weight-load time (nn.Linear weights of the image tower's blocks) and by
+// the unit API; the activations of the fp8 path are quantised inside their producing kernels
+// (layernorm.hip, attention.hip, the c_fc epilogue of gemm_mx8.hip).
+#include "common.h"
+#include "kernels.h"
+
+namespace tapclip {
+namespace {
+
+// one thread per 32-block: 128 B in, 32 B + 1 scale byte out
+__global__ __launch_bounds__(256) void quantize_mx8_kernel(const float* __restrict__ x, int64_t rows, int K, int64_t ldx,
+                                                           int64_t scale_rows, float scale, uint8_t* __restrict__ q, int64_t ldq,
+                                                           uint8_t* __restrict__ sc, int64_t rows_pad) {
+  const int bpr = K / 32;
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= rows * bpr) return;
+  const int64_t row = id / bpr;
+  const int b = (int)(id - row * bpr);
+  const float mul = row < scale_rows ? scale : 1.f;
+  const float4* src = reinterpret_cast<const float4*>(x + row * ldx + b * 32);
+  float4 v[8];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v[i] = src[i];
+    v[i].x *= mul; v[i].y *= mul; v[i].z *= mul; v[i].w *= mul;
+    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
+  }
+  const uint32_t byte = mx8_scale_byte(amax);
+  const float inv = mx8_inv_scale(byte);
+  uint4 o[2];
+  uint32_t* ow = reinterpret_cast<uint32_t*>(o);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ow[i] = mx8_pack4(v[i].x, v[i].y, v[i].z, v[i].w, inv);
+  uint4* dst = reinterpret_cast<uint4*>(q + row * ldq + b * 32);
+  dst[0] = o[0];
+  dst[1] = o[1];
+  sc[mx8_scale_index(row, b, rows_pad)] = (uint8_t)byte;
+}
+
+}  // namespace
+
+hipError_t launch_quantize_mx8(const float* x, int64_t rows, int32_t K, int64_t ldx, int64_t scale_rows, float scale, uint8_t* q,
+                               int64_t ldq, uint8_t* sc, int64_t rows_pad, hipStream_t s) {
+  if (rows <= 0 || K <= 0 || K % 64 != 0 || ldx % 4 != 0 || ldq % 16 != 0 || rows_pad < rows) return hipErrorInvalidValue;
+  const int64_t n = rows * (K / 32);
+  hipLaunchKernelGGL(quantize_mx8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, rows, K, ldx, scale_rows, scale, q, ldq, sc,
+                     rows_pad);
+  return hipGetLastError();
+}
+
+}  // namespace tapclip

@@ -699,6 +699,17 @@ int tapclip_gemm_f32(const float* A, const float* W, const float* bias, int64_t 
   const bool split = precision == TAPCLIP_PREC_BF16X3;
   hipStream_t s = static_cast<hipStream_t>(stream);
   char* p = static_cast<char*>(scratch);
+  if (precision == TAPCLIP_PREC_FP8) {  // quantise both operands to MXFP8, then the block-scaled MFMA GEMM
+    if (N % 256 != 0 || K < 256) return fail(TAPCLIP_EINVAL, "fp8 gemm needs N %% 256 == 0 and K >= 256 (N %d K %d)", N, K);
+    const int64_t m_pad = (M + 7) / 8 * 8;
+    uint8_t* aq = reinterpret_cast<uint8_t*>(p); p += align_up((size_t)M * K);
+    uint8_t* as = reinterpret_cast<uint8_t*>(p); p += align_up((size_t)(K / 64) * m_pad * 2);
+    uint8_t* wq = reinterpret_cast<uint8_t*>(p); p += align_up((size_t)N * K);
+    uint8_t* ws = reinterpret_cast<uint8_t*>(p);
+    HIP_TRY(launch_quantize_mx8(A, M, K, K, 0, 1.f, aq, K, as, m_pad, s));
+    HIP_TRY(launch_quantize_mx8(W, N, K, K, 0, 1.f, wq, K, ws, N, s));
+    return tapclip_mx8_gemm(aq, as, M, m_pad, wq, ws, bias, N, K, 0, 0, C, nullptr, nullptr, stream);
+  }
   bf16_t* a_hi = reinterpret_cast<bf16_t*>(p); p += align_up((size_t)M * K * 2);
   bf16_t* a_lo = reinterpret_cast<bf16_t*>(p); p += align_up((size_t)M * K * 2);
   bf16_t* w_hi = reinterpret_cast<bf16_t*>(p); p += align_up((size_t)N * K * 2);
@@ -713,6 +724,37 @@ int tapclip_gemm_f32(const float* A, const float* W, const float* bias, int64_t 
   g.out_hi = nullptr; g.out_lo = nullptr; g.out_f32 = C; g.ldo = N;
   g.add_table = nullptr; g.rows_per_group = 0; g.act = 0;
   HIP_TRY(launch_gemm(g, EPI_BIAS_F32, split, s));
+  return TAPCLIP_OK;
+}
+
+int tapclip_mx8_quantize(const float* x, int64_t rows, int32_t K, uint8_t* q, uint8_t* scales, int64_t rows_pad,
+                         tapclip_stream_t stream) {
+  if (!x || !q || !scales) return fail(TAPCLIP_EINVAL, "null argument");
+  if (rows <= 0 || K <= 0 || K % 64 != 0 || rows_pad < rows) return fail(TAPCLIP_EINVAL, "mx8_quantize needs K %% 64 == 0 and rows_pad >= rows (rows %lld K %d rows_pad %lld)", (long long)rows, K, (long long)rows_pad);
+  HIP_TRY(launch_quantize_mx8(x, rows, K, K, 0, 1.f, q, K, scales, rows_pad, static_cast<hipStream_t>(stream)));
+  return TAPCLIP_OK;
+}
+
+int tapclip_mx8_gemm(const uint8_t* a_q, const uint8_t* a_scale, int64_t M, int64_t m_pad, const uint8_t* w_q,
+                     const uint8_t* w_scale, const float* bias, int32_t N, int32_t K, int32_t epilogue, int32_t act,
+                     float* out_f32, uint8_t* out_q, uint8_t* out_q_scale, tapclip_stream_t stream) {
+  if (!a_q || !a_scale || !w_q || !w_scale) return fail(TAPCLIP_EINVAL, "null argument");
+  Mx8GemmArgs g;
+  g.A = a_q; g.A_scale = a_scale; g.lda = K; g.m_pad = m_pad;
+  g.W = w_q; g.W_scale = w_scale; g.bias = bias;
+  g.M = M; g.N = N; g.K = K; g.act = act;
+  int epi;
+  if (epilogue == 0) {
+    if (!out_f32) return fail(TAPCLIP_EINVAL, "epilogue 0 needs out_f32");
+    g.out_f32 = out_f32; g.ldo = N; epi = EPI_BIAS_F32;
+  } else if (epilogue == 1) {
+    if (!out_q || !out_q_scale) return fail(TAPCLIP_EINVAL, "epilogue 1 needs out_q and out_q_scale");
+    g.out_q = out_q; g.out_q_scale = out_q_scale; g.out_m_pad = m_pad; g.ldo = N; epi = EPI_BIAS_GELU_MX8;
+  } else {
+    return fail(TAPCLIP_EINVAL, "bad mx8 epilogue %d", epilogue);
+  }
+  if (!gemm_mx8_supports(g)) return fail(TAPCLIP_EINVAL, "mx8 gemm needs N %% 256 == 0, K %% 64 == 0, K >= 256, m_pad %% 8 == 0 (M %lld N %d K %d m_pad %lld)", (long long)M, N, K, (long long)m_pad);
+  HIP_TRY(launch_gemm_mx8(g, epi, static_cast<hipStream_t>(stream)));
   return TAPCLIP_OK;
 }
 

@@ -290,3 +290,41 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         _lib.check(lib.tapclip_gemm_f32(_ptr(aa), _ptr(ww), _ptr(bb), M, N, K, _lib.PRECISIONS[precision], _ptr(out),
                                         _ptr(scratch), nbytes, _stream_ptr(aa.device)))
     return out
+
+
+def mx8_quantize(x: torch.Tensor):
+    """fp32 [rows, K] -> (e4m3 bytes [rows, K], e8m0 scale bytes [K/64, rows_pad, 2]): the fp8 path's operand
+    format (include/tapclip.h tapclip_mx8_quantize)."""
+    xx = x.detach().to(torch.float32).contiguous()
+    rows, K = xx.shape
+    rows_pad = (rows + 7) // 8 * 8
+    q = torch.empty(rows, K, dtype=torch.uint8, device=xx.device)
+    sc = torch.zeros(K // 64, rows_pad, 2, dtype=torch.uint8, device=xx.device)
+    with torch.cuda.device(xx.device):
+        _lib.check(_lib.load().tapclip_mx8_quantize(_ptr(xx), rows, K, _ptr(q), _ptr(sc), rows_pad, _stream_ptr(xx.device)))
+    return q, sc
+
+
+def mx8_gemm(a_q: torch.Tensor, a_scale: torch.Tensor, w_q: torch.Tensor, w_scale: torch.Tensor,
+             bias: Optional[torch.Tensor] = None, epilogue: str = "f32", act: int = 0):
+    """dequant(a) @ dequant(w).T + bias on the MXFP8 MFMA kernel.  epilogue "f32": fp32 [M, N];
+    "gelu_mx8": (e4m3 bytes [M, N], scale bytes [N/64, m_pad, 2]) of act(.) re-quantised (the c_fc epilogue)."""
+    M, K = a_q.shape
+    N = w_q.shape[0]
+    m_pad = a_scale.shape[1]
+    dev = a_q.device
+    bb = None if bias is None else bias.detach().to(device=dev, dtype=torch.float32).contiguous()
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        if epilogue == "f32":
+            out = torch.empty(M, N, dtype=torch.float32, device=dev)
+            _lib.check(lib.tapclip_mx8_gemm(_ptr(a_q), _ptr(a_scale), M, m_pad, _ptr(w_q), _ptr(w_scale), _ptr(bb), N, K, 0, act,
+                                            _ptr(out), None, None, _stream_ptr(dev)))
+            return out
+        if epilogue != "gelu_mx8":
+            raise ValueError(f"unknown mx8 epilogue {epilogue!r}")
+        oq = torch.empty(M, N, dtype=torch.uint8, device=dev)
+        osc = torch.zeros(N // 64, m_pad, 2, dtype=torch.uint8, device=dev)
+        _lib.check(lib.tapclip_mx8_gemm(_ptr(a_q), _ptr(a_scale), M, m_pad, _ptr(w_q), _ptr(w_scale), _ptr(bb), N, K, 1, act,
+                                        None, _ptr(oq), _ptr(osc), _stream_ptr(dev)))
+        return oq, osc
