@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_FP8_TFLOPS = 5000.0   # dense, block-scaled v_mfma_scale_f32_*_f8f6f4 with e4m3 operands (same guide)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -61,7 +62,7 @@ def main():
     ap.add_argument("--model", default="ViT-B-16")
     ap.add_argument("--classes", type=int, default=65)
     ap.add_argument("--prompt-len", type=int, default=16)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"],
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "fp8"],
                     help="bf16 = the benchmarked fast path; bf16x3 = the split-bf16 parity mode (3 MFMA products)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-forward", action="store_true")
@@ -187,10 +188,16 @@ def main():
                 traffic = json.load(open(tpath)).get("gemm_family_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        fp8 = args.precision == "fp8"
+        peak = PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS
+        if fp8:
+            traffic = None  # the committed PMC passes are of the bf16 kernels
         result["roofline"] = {
-            "kernel": "gemm256_kernel<EPI,false,256,4> (persistent bf16 MFMA 16x16x32 GEMM, 256x256 tiles, 4-stage LDS-DMA ring): the QKV + out_proj + c_fc/GELU + c_proj launches",
-            "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            "kernel": ("gemm_mx8_kernel<EPI> (persistent MXFP8 MFMA 32x32x64 GEMM, 256x256 tiles, 4-stage LDS-DMA ring with e8m0 scales): the QKV + out_proj + c_fc/GELU + c_proj launches"
+                       if fp8 else
+                       "gemm256_kernel<EPI,false,256,4> (persistent bf16 MFMA 16x16x32 GEMM, 256x256 tiles, 4-stage LDS-DMA ring): the QKV + out_proj + c_fc/GELU + c_proj launches"),
+            "bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": traffic,
             "traffic_note": "bytes/launch at the L2 fabric side (FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits included) from profiles/r01_pmc_traffic_bench.json; algorithmic operand+output bytes per launch average 313 MB",
             "flops_per_launch": round(g_fl / g_n), "avg_launch_us": round(1e3 * g_ms / g_n, 2), "launches_per_step": g_n / args.steps,
         }

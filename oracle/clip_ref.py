@@ -99,7 +99,17 @@ def _rb(x: torch.Tensor, emulate: Optional[str]) -> torch.Tensor:
         return x.to(torch.bfloat16).to(torch.float32)
     if emulate == "fp16":
         return x.to(torch.float16).to(torch.float32)
+    if emulate == "mx8":  # the fp8 path keeps bf16 wherever it is not an MXFP8 GEMM operand
+        return x.to(torch.bfloat16).to(torch.float32)
     raise ValueError(emulate)
+
+
+def _rq(x: torch.Tensor, emulate: Optional[str]) -> torch.Tensor:
+    """Rounding of a block-GEMM operand (k = last dim): MXFP8 on the fp8 path (oracle/mx8_ref.py), else as _rb."""
+    if emulate == "mx8":
+        from . import mx8_ref
+        return mx8_ref.fake_quant(x)
+    return _rb(x, emulate)
 
 
 def _act(x: torch.Tensor, quick: bool) -> torch.Tensor:
@@ -133,7 +143,7 @@ def block_forward(
     b_in = g("attn.in_proj_bias")
     if emulate:
         # the kernels fold 1/sqrt(hd) (a power of two for hd = 64) into Wq, bq
-        qkv = F.linear(_rb(h, emulate), _rb(w_in, emulate), b_in)
+        qkv = F.linear(_rq(h, emulate), _rq(w_in, emulate), b_in)
     else:
         qkv = F.linear(h, w_in, b_in)
     if taps is not None:
@@ -159,17 +169,17 @@ def block_forward(
     if taps is not None:
         taps["probs"] = p
         taps["attn_ctx"] = o
-    a = F.linear(_rb(o, emulate), _rb(g("attn.out_proj.weight"), emulate), g("attn.out_proj.bias"))
+    a = F.linear(_rq(o, emulate), _rq(g("attn.out_proj.weight"), emulate), g("attn.out_proj.bias"))
     if taps is not None:
         taps["attn_out"] = a
     x = x + _rb(a, emulate)  # the kernels hand the branch to the next LayerNorm kernel as bf16
 
     h = F.layer_norm(x, (D,), g("ln_2.weight"), g("ln_2.bias"), 1e-5)
-    h = F.linear(_rb(h, emulate), _rb(g("mlp.c_fc.weight"), emulate), g("mlp.c_fc.bias"))
+    h = F.linear(_rq(h, emulate), _rq(g("mlp.c_fc.weight"), emulate), g("mlp.c_fc.bias"))
     h = _act(h, quick_gelu)
     if taps is not None:
         taps["mlp_hidden"] = h
-    h = F.linear(_rb(h, emulate), _rb(g("mlp.c_proj.weight"), emulate), g("mlp.c_proj.bias"))
+    h = F.linear(_rq(h, emulate), _rq(g("mlp.c_proj.weight"), emulate), g("mlp.c_proj.bias"))
     x = x + _rb(h, emulate)
     if taps is not None:
         taps["out"] = x

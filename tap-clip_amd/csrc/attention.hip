@@ -34,6 +34,33 @@ __device__ __forceinline__ bf16x8_t tr_pair(const uint8_t* base0, const uint8_t*
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// MXFP8 store of one query row's head slice: lane (r, g) holds O[q][16 dt + 4 g + e] * 1/sum for dt = 0..3.  The
+// head's 64 columns are two 32-blocks (dt 0,1 | dt 2,3), each spread over the row's four g-lanes.  Called by all
+// lanes (the shuffles need them); `valid` masks the stores.
+__device__ __forceinline__ void store_o_mx8(const AttnArgs& a, const f32x4_t (&oc)[4], float inv, int64_t row, int head, int g,
+                                            bool valid) {
+  float am[2] = {0.f, 0.f};
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) am[dt >> 1] = fmaxf(am[dt >> 1], fabsf(oc[dt][e] * inv));
+  uint32_t byte[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    am[b] = fmaxf(am[b], __shfl_xor(am[b], 16, 64));
+    am[b] = fmaxf(am[b], __shfl_xor(am[b], 32, 64));
+    byte[b] = mx8_scale_byte(am[b]);
+  }
+  if (!valid) return;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    const float is = mx8_inv_scale(byte[dt >> 1]);
+    *reinterpret_cast<uint32_t*>(a.out_q + row * a.D + head * 64 + 16 * dt + 4 * g) =
+        mx8_pack4(oc[dt][0] * inv, oc[dt][1] * inv, oc[dt][2] * inv, oc[dt][3] * inv, is);
+  }
+  if (g == 0) *reinterpret_cast<uint16_t*>(a.out_q_scale + ((size_t)head * a.out_m_pad + row) * 2) = (uint16_t)(byte[0] | (byte[1] << 8));
+}
+
 template <int NKT, bool SPLIT>
 __global__ __launch_bounds__(512) void attn_kernel(AttnArgs a) {
   constexpr int KEYS = NKT * 16;
@@ -222,7 +249,9 @@ __global__ __launch_bounds__(512) void attn_kernel(AttnArgs a) {
     }
 
     // ---- store: lane holds O[q = qi][d = 16*dt + 4*g + e]
-    if (qi < T) {
+    if (!SPLIT && a.out_q != nullptr) {  // (kernel-uniform)
+      store_o_mx8(a, oc, inv, row0 + qi, head, g, qi < T);
+    } else if (qi < T) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         const int64_t off = (row0 + qi) * D + head * 64 + 16 * dt + 4 * g;
@@ -424,7 +453,9 @@ __global__ __launch_bounds__(512) void attn_flash_kernel(AttnArgs a) {
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
-    if (qi < T) {
+    if (!SPLIT && a.out_q != nullptr) {
+      store_o_mx8(a, oc[t], inv, row0 + qi, head, g, qi < T);
+    } else if (qi < T) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         const int64_t off = (row0 + qi) * D + head * 64 + 16 * dt + 4 * g;

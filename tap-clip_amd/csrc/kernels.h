@@ -81,6 +81,9 @@ hipError_t launch_layernorm(const float* x, int64_t ldx, const float* gamma, con
 hipError_t launch_add_layernorm(float* x, const bf16_t* delta_hi, const bf16_t* delta_lo, const float* gamma,
                                 const float* beta, int64_t rows, int32_t d, bf16_t* out_hi, bf16_t* out_lo,
                                 hipStream_t s);
+// LayerNorm (optionally after x += delta) with MXFP8 output: out_q [rows, d] e4m3 + out_sc [d/64][rows_pad][2]
+hipError_t launch_layernorm_mx8(float* x, const bf16_t* delta_hi, const float* gamma, const float* beta, int64_t rows, int32_t d,
+                                uint8_t* out_q, uint8_t* out_sc, int64_t rows_pad, hipStream_t s);
 // x[i] += delta_hi[i] (+ delta_lo[i])
 hipError_t launch_add_delta(float* x, const bf16_t* delta_hi, const bf16_t* delta_lo, int64_t n, hipStream_t s);
 
@@ -92,6 +95,11 @@ struct AttnArgs {
   float* probs;          // nullable [n, H, T, T] fp32 softmax probabilities
   int32_t n_seq, T, H, D;
   int32_t causal;
+  // fp8 path: when out_q is set the output leaves as MXFP8 (e4m3 [n*T, D] + scales [D/64][out_m_pad][2]; a head's
+  // 64 columns are one k-step of the out_proj GEMM) instead of bf16
+  uint8_t* out_q = nullptr;
+  uint8_t* out_q_scale = nullptr;
+  int64_t out_m_pad = 0;
 };
 hipError_t launch_attention(const AttnArgs& a, bool split, hipStream_t s);
 

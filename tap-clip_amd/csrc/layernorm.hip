@@ -8,7 +8,7 @@
 namespace tapclip {
 namespace {
 
-// MODE 0: bf16 hi   1: bf16 hi + lo   2: fp32
+// MODE 0: bf16 hi   1: bf16 hi + lo   2: fp32   3: MXFP8 (e4m3 bytes + one e8m0 scale per 32 columns; vector kernel only)
 // ADD: the row first receives the pending residual branch, x += delta (bf16 hi [+ lo], the output of the
 // preceding out_proj / c_proj GEMM), and the updated fp32 row is written back before it is normalised.
 template <int MODE, int NV, bool ADD>  // NV float4 per lane: d = 256 * NV
@@ -16,7 +16,8 @@ __global__ __launch_bounds__(256) void ln_vec_kernel(float* __restrict__ x, int6
                                                      const bf16_t* __restrict__ d_hi, const bf16_t* __restrict__ d_lo,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, int64_t rows, int d,
-                                                     bf16_t* out_hi, bf16_t* out_lo, float* out_f32) {
+                                                     bf16_t* out_hi, bf16_t* out_lo, float* out_f32,
+                                                     uint8_t* out_q, uint8_t* out_sc, int64_t rows_pad) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -55,7 +56,16 @@ __global__ __launch_bounds__(256) void ln_vec_kernel(float* __restrict__ x, int6
     const float4 bt = *reinterpret_cast<const float4*>(beta + c);
     float y[4] = {v[j].x * rstd * gm.x + bt.x, v[j].y * rstd * gm.y + bt.y, v[j].z * rstd * gm.z + bt.z,
                   v[j].w * rstd * gm.w + bt.w};
-    if (MODE == 2) {
+    if (MODE == 3) {
+      // a 32-block of the row = the 4 values of 8 consecutive lanes: block maximum by three xor-shuffles
+      float am = fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3])));
+      am = fmaxf(am, __shfl_xor(am, 1, 64));
+      am = fmaxf(am, __shfl_xor(am, 2, 64));
+      am = fmaxf(am, __shfl_xor(am, 4, 64));
+      const uint32_t byte = mx8_scale_byte(am);
+      *reinterpret_cast<uint32_t*>(out_q + row * d + c) = mx8_pack4(y[0], y[1], y[2], y[3], mx8_inv_scale(byte));
+      if ((lane & 7) == 0) out_sc[mx8_scale_index(row, c >> 5, rows_pad)] = (uint8_t)byte;
+    } else if (MODE == 2) {
       *reinterpret_cast<float4*>(out_f32 + row * d + c) = make_float4(y[0], y[1], y[2], y[3]);
     } else {
       bf16_t h[4], l[4];
@@ -124,17 +134,19 @@ __global__ __launch_bounds__(256) void ln_generic_kernel(float* __restrict__ x, 
 
 template <int MODE, bool ADD>
 hipError_t launch_mode(float* x, int64_t ldx, const bf16_t* dh, const bf16_t* dl, const float* gamma, const float* beta,
-                       int64_t rows, int32_t d, bf16_t* hi, bf16_t* lo, float* f32, hipStream_t s) {
+                       int64_t rows, int32_t d, bf16_t* hi, bf16_t* lo, float* f32, hipStream_t s, uint8_t* q = nullptr,
+                       uint8_t* qs = nullptr, int64_t rows_pad = 0) {
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   if (d % 256 == 0 && d / 256 <= 4 && ldx % 4 == 0) {
     switch (d / 256) {
-      case 1: hipLaunchKernelGGL((ln_vec_kernel<MODE, 1, ADD>), grid, block, 0, s, x, ldx, dh, dl, gamma, beta, rows, d, hi, lo, f32); break;
-      case 2: hipLaunchKernelGGL((ln_vec_kernel<MODE, 2, ADD>), grid, block, 0, s, x, ldx, dh, dl, gamma, beta, rows, d, hi, lo, f32); break;
-      case 3: hipLaunchKernelGGL((ln_vec_kernel<MODE, 3, ADD>), grid, block, 0, s, x, ldx, dh, dl, gamma, beta, rows, d, hi, lo, f32); break;
-      default: hipLaunchKernelGGL((ln_vec_kernel<MODE, 4, ADD>), grid, block, 0, s, x, ldx, dh, dl, gamma, beta, rows, d, hi, lo, f32); break;
+      case 1: hipLaunchKernelGGL((ln_vec_kernel<MODE, 1, ADD>), grid, block, 0, s, x, ldx, dh, dl, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+      case 2: hipLaunchKernelGGL((ln_vec_kernel<MODE, 2, ADD>), grid, block, 0, s, x, ldx, dh, dl, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+      case 3: hipLaunchKernelGGL((ln_vec_kernel<MODE, 3, ADD>), grid, block, 0, s, x, ldx, dh, dl, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+      default: hipLaunchKernelGGL((ln_vec_kernel<MODE, 4, ADD>), grid, block, 0, s, x, ldx, dh, dl, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
     }
   } else {
-    hipLaunchKernelGGL((ln_generic_kernel<MODE, ADD>), grid, block, 0, s, x, ldx, dh, dl, gamma, beta, rows, d, hi, lo, f32);
+    if constexpr (MODE == 3) return hipErrorInvalidValue;  // MXFP8 output: widths 256 .. 1024 only
+    else hipLaunchKernelGGL((ln_generic_kernel<MODE, ADD>), grid, block, 0, s, x, ldx, dh, dl, gamma, beta, rows, d, hi, lo, f32);
   }
   return hipGetLastError();
 }
@@ -156,6 +168,15 @@ hipError_t launch_add_layernorm(float* x, const bf16_t* delta_hi, const bf16_t* 
   if (rows <= 0 || d <= 0 || d % 64 != 0 || delta_hi == nullptr) return hipErrorInvalidValue;
   if (out_lo != nullptr) return launch_mode<1, true>(x, d, delta_hi, delta_lo, gamma, beta, rows, d, out_hi, out_lo, nullptr, s);
   return launch_mode<0, true>(x, d, delta_hi, delta_lo, gamma, beta, rows, d, out_hi, nullptr, nullptr, s);
+}
+
+// MXFP8 output (the A operand of the fp8 path's QKV / c_fc GEMMs): out_q [rows, d] e4m3, out_sc [d/64][rows_pad][2].
+// delta_hi == nullptr: plain LayerNorm; else x += delta first (written back), as launch_add_layernorm.
+hipError_t launch_layernorm_mx8(float* x, const bf16_t* delta_hi, const float* gamma, const float* beta, int64_t rows, int32_t d,
+                                uint8_t* out_q, uint8_t* out_sc, int64_t rows_pad, hipStream_t s) {
+  if (rows <= 0 || d <= 0 || d % 256 != 0 || d > 1024 || rows_pad < rows || !out_q || !out_sc) return hipErrorInvalidValue;
+  if (delta_hi == nullptr) return launch_mode<3, false>(x, d, nullptr, nullptr, gamma, beta, rows, d, nullptr, nullptr, nullptr, s, out_q, out_sc, rows_pad);
+  return launch_mode<3, true>(x, d, delta_hi, nullptr, gamma, beta, rows, d, nullptr, nullptr, nullptr, s, out_q, out_sc, rows_pad);
 }
 
 }  // namespace tapclip

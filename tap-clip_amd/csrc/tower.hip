@@ -51,9 +51,15 @@ struct Packed {  // a [rows, ld] bf16 matrix (hi, and lo for bf16x3)
   bf16_t* lo = nullptr;
 };
 
+struct PackedMx8 {  // a [rows, K] MXFP8 matrix: e4m3 bytes + e8m0 scales [K/64][rows][2]
+  uint8_t* q = nullptr;
+  uint8_t* s = nullptr;
+};
+
 struct LayerW {
   float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
   Packed wqkv, wo, wfc, wpr;
+  PackedMx8 qqkv, qo, qfc, qpr;  // fp8 precision: the block GEMM weights as MXFP8 (instead of the bf16 copies)
   Packed wqkv_t, wo_t, wfc_t, wpr_t;  // text towers: transposed copies [K, N] for the dX GEMMs of the backward
   float *bqkv = nullptr, *bo = nullptr, *bfc = nullptr, *bpr = nullptr;
 };
@@ -70,6 +76,7 @@ size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 struct tapclip_tower {
   tapclip_tower_cfg cfg;
   bool split = false;
+  bool fp8 = false;       // TAPCLIP_PREC_FP8: block GEMMs on MXFP8 (image tower only)
   int tokens_vision = 0;  // G*G + 1
   int Kp = 0;             // padded 3*p*p
   std::vector<LayerW> layers;
@@ -100,6 +107,10 @@ struct Workspace {
   bf16_t *h_hi = nullptr, *h_lo = nullptr;
   bf16_t *d_hi = nullptr, *d_lo = nullptr;  // pending residual branch (out_proj / c_proj output)
   float* probs = nullptr;
+  // fp8 precision: MXFP8 activations live in the front of the bf16 buffers they replace (e4m3 [M, K] then the
+  // scales [K/64][m_pad][2]: 1.03 bytes per element against 2)
+  uint8_t *xn_q = nullptr, *xn_s = nullptr, *ao_q = nullptr, *ao_s = nullptr, *h_q = nullptr, *h_s = nullptr;
+  int64_t m_pad = 0;
   size_t bytes = 0;
 };
 
@@ -134,6 +145,16 @@ Workspace carve(const tapclip_tower* t, int64_t n_seq, int tokens, void* base) {
   }
   if (t->cfg.kind == TAPCLIP_TOWER_TEXT)
     w.probs = static_cast<float*>(take((size_t)n_seq * t->cfg.heads * tokens * tokens * 4));
+  if (t->fp8) {
+    w.m_pad = (M + 7) / 8 * 8;
+    auto view = [&](bf16_t* buf, int64_t K, uint8_t*& q, uint8_t*& sc) {
+      q = reinterpret_cast<uint8_t*>(buf);
+      sc = buf ? q + align_up((size_t)M * K) : nullptr;
+    };
+    view(w.xn_hi, D, w.xn_q, w.xn_s);
+    view(w.ao_hi, D, w.ao_q, w.ao_s);
+    view(w.h_hi, F, w.h_q, w.h_s);
+  }
   w.bytes = off;
   return w;
 }
@@ -193,6 +214,18 @@ int own_packed(tapclip_tower* t, const float* src, int64_t rows, int cols, int d
   return TAPCLIP_OK;
 }
 
+int own_packed_mx8(tapclip_tower* t, const float* src, int64_t rows, int cols, int64_t scale_rows, float scale, PackedMx8* out,
+                   hipStream_t s) {
+  void *q, *sc;
+  int rc = dev_alloc(t, rows * cols, &q);
+  if (rc) return rc;
+  if ((rc = dev_alloc(t, (size_t)(cols / 64) * rows * 2, &sc))) return rc;
+  HIP_TRY(launch_quantize_mx8(src, rows, cols, cols, scale_rows, scale, static_cast<uint8_t*>(q), cols, static_cast<uint8_t*>(sc), rows, s));
+  out->q = static_cast<uint8_t*>(q);
+  out->s = static_cast<uint8_t*>(sc);
+  return TAPCLIP_OK;
+}
+
 bool shape_is(const int64_t* shape, int ndim, std::initializer_list<int64_t> want) {
   if (ndim != (int)want.size()) return false;
   int i = 0;
@@ -227,6 +260,55 @@ int gemm(tapclip_tower* t, int slot, int epi, const bf16_t* a_hi, const bf16_t* 
   g.act = t->cfg.act;
   ProfScope ps(t, slot, s);
   HIP_TRY(launch_gemm(g, epi, t->split, s));
+  return TAPCLIP_OK;
+}
+
+int gemm_mx8(tapclip_tower* t, int slot, int epi, const uint8_t* a_q, const uint8_t* a_s, int64_t m_pad, const PackedMx8& w,
+             const float* bias, int64_t M, int N, int K, bf16_t* o_bf16, uint8_t* o_q, uint8_t* o_s, hipStream_t s) {
+  Mx8GemmArgs g;
+  g.A = a_q; g.A_scale = a_s; g.lda = K; g.m_pad = m_pad;
+  g.W = w.q; g.W_scale = w.s; g.bias = bias;
+  g.M = M; g.N = N; g.K = K;
+  g.out_bf16 = o_bf16; g.out_q = o_q; g.out_q_scale = o_s; g.out_m_pad = m_pad; g.ldo = N;
+  g.act = t->cfg.act;
+  ProfScope ps(t, slot, s);
+  HIP_TRY(launch_gemm_mx8(g, epi, s));
+  return TAPCLIP_OK;
+}
+
+// The fp8 precision of the image tower (BASELINE.json configs[4]): the same block, with the four GEMMs on the
+// block-scaled MXFP8 MFMA.  Their A operands are quantised where they are produced -- LayerNorm (layernorm.hip
+// MODE 3), the attention core's output (attention.hip store_o_mx8), the GELU epilogue of c_fc (gemm_mx8.hip) --
+// q|k|v and the two residual branches stay bf16, the residual stream fp32.
+int run_blocks_fp8(tapclip_tower* t, float* x, int64_t n_seq, int tokens, const Workspace& w, hipStream_t s) {
+  const int64_t M = n_seq * tokens;
+  const int D = t->cfg.width, F = t->cfg.mlp_dim, H = t->cfg.heads;
+  int rc;
+  for (int li = 0; li < t->cfg.layers; ++li) {
+    const LayerW& L = t->layers[li];
+    {
+      ProfScope ps(t, 1, s);
+      HIP_TRY(launch_layernorm_mx8(x, li == 0 ? nullptr : w.d_hi, L.ln1_g, L.ln1_b, M, D, w.xn_q, w.xn_s, w.m_pad, s));
+    }
+    if ((rc = gemm_mx8(t, 2, EPI_BIAS_BF16, w.xn_q, w.xn_s, w.m_pad, L.qqkv, L.bqkv, M, 3 * D, D, w.qkv_hi, nullptr, nullptr, s))) return rc;
+    {
+      AttnArgs a;
+      a.qkv_hi = w.qkv_hi; a.qkv_lo = nullptr;
+      a.out_hi = nullptr; a.out_lo = nullptr;
+      a.out_q = w.ao_q; a.out_q_scale = w.ao_s; a.out_m_pad = w.m_pad;
+      a.probs = nullptr;
+      a.n_seq = (int)n_seq; a.T = tokens; a.H = H; a.D = D; a.causal = 0;
+      ProfScope ps(t, 3, s);
+      HIP_TRY(launch_attention(a, false, s));
+    }
+    if ((rc = gemm_mx8(t, 4, EPI_BIAS_BF16, w.ao_q, w.ao_s, w.m_pad, L.qo, L.bo, M, D, D, w.d_hi, nullptr, nullptr, s))) return rc;
+    {
+      ProfScope ps(t, 1, s);
+      HIP_TRY(launch_layernorm_mx8(x, w.d_hi, L.ln2_g, L.ln2_b, M, D, w.xn_q, w.xn_s, w.m_pad, s));
+    }
+    if ((rc = gemm_mx8(t, 5, EPI_BIAS_GELU_MX8, w.xn_q, w.xn_s, w.m_pad, L.qfc, L.bfc, M, F, D, nullptr, w.h_q, w.h_s, s))) return rc;
+    if ((rc = gemm_mx8(t, 6, EPI_BIAS_BF16, w.h_q, w.h_s, w.m_pad, L.qpr, L.bpr, M, D, F, w.d_hi, nullptr, nullptr, s))) return rc;
+  }
   return TAPCLIP_OK;
 }
 
@@ -388,11 +470,16 @@ int tapclip_tower_create(const tapclip_tower_cfg* cfg, tapclip_tower_t** out) {
   if (cfg->heads <= 0 || cfg->width != cfg->heads * 64) return fail(TAPCLIP_EINVAL, "head dim must be 64 (width %d, heads %d)", cfg->width, cfg->heads);
   if (cfg->mlp_dim <= 0 || cfg->mlp_dim % 128 != 0) return fail(TAPCLIP_EINVAL, "mlp_dim %d must be a positive multiple of 128", cfg->mlp_dim);
   if (cfg->layers <= 0 || cfg->embed_dim <= 0 || cfg->embed_dim > 1024) return fail(TAPCLIP_EINVAL, "bad layers/embed_dim");
-  if (cfg->precision != TAPCLIP_PREC_BF16 && cfg->precision != TAPCLIP_PREC_BF16X3) return fail(TAPCLIP_EINVAL, "bad precision %d", cfg->precision);
+  if (cfg->precision != TAPCLIP_PREC_BF16 && cfg->precision != TAPCLIP_PREC_BF16X3 && cfg->precision != TAPCLIP_PREC_FP8) return fail(TAPCLIP_EINVAL, "bad precision %d", cfg->precision);
+  if (cfg->precision == TAPCLIP_PREC_FP8) {
+    if (cfg->kind != TAPCLIP_TOWER_VISION) return fail(TAPCLIP_EINVAL, "TAPCLIP_PREC_FP8 is an image-tower precision (the text tower is differentiated: use bf16 / bf16x3)");
+    if (cfg->width % 256 != 0 || cfg->width > 1024 || cfg->mlp_dim % 256 != 0 || cfg->mlp_dim > 4096) return fail(TAPCLIP_EINVAL, "TAPCLIP_PREC_FP8 needs width %% 256 == 0 (<= 1024) and mlp_dim %% 256 == 0 (<= 4096), got %d / %d", cfg->width, cfg->mlp_dim);
+  }
   if (cfg->act != TAPCLIP_ACT_GELU_ERF && cfg->act != TAPCLIP_ACT_QUICK_GELU) return fail(TAPCLIP_EINVAL, "bad activation %d", cfg->act);
   tapclip_tower* t = new tapclip_tower();
   t->cfg = *cfg;
   t->split = cfg->precision == TAPCLIP_PREC_BF16X3;
+  t->fp8 = cfg->precision == TAPCLIP_PREC_FP8;
   t->layers.resize(cfg->layers);
   if (cfg->kind == TAPCLIP_TOWER_VISION) {
     if (cfg->patch <= 0 || cfg->image_size <= 0 || cfg->image_size % cfg->patch != 0) {
@@ -472,6 +559,13 @@ int tapclip_tower_load_weight(tapclip_tower_t* t, const char* key_c, const float
     else if (sub == "ln_1.bias") rc = vec(D, &L.ln1_b);
     else if (sub == "ln_2.weight") rc = vec(D, &L.ln2_g);
     else if (sub == "ln_2.bias") rc = vec(D, &L.ln2_b);
+    else if (t->fp8 && (sub == "attn.in_proj_weight" || sub == "attn.out_proj.weight" || sub == "mlp.c_fc.weight" || sub == "mlp.c_proj.weight")) {
+      // fp8 precision: the block GEMM weights are kept as MXFP8 only (1/sqrt(64) folded into the q rows first)
+      const bool qkv = sub == "attn.in_proj_weight", fc = sub == "mlp.c_fc.weight", pr = sub == "mlp.c_proj.weight";
+      const int64_t rows = qkv ? 3 * D : fc ? F : D, cols = pr ? F : D;
+      if (!shape_is(shape, ndim, {rows, cols})) return bad(("[" + std::to_string(rows) + "," + std::to_string(cols) + "]").c_str());
+      rc = own_packed_mx8(t, src, rows, (int)cols, qkv ? D : 0, qkv ? qscale : 1.f, qkv ? &L.qqkv : fc ? &L.qfc : pr ? &L.qpr : &L.qo, s);
+    }
     else if (sub == "attn.in_proj_weight") rc = mat(3 * D, D, &L.wqkv, &L.wqkv_t, D, qscale);
     else if (sub == "attn.in_proj_bias") rc = vec(3 * D, &L.bqkv, D, qscale);
     else if (sub == "attn.out_proj.weight") rc = mat(D, D, &L.wo, &L.wo_t);
@@ -560,7 +654,7 @@ int tapclip_encode_image(tapclip_tower_t* t, const float* images, int32_t B, flo
     ProfScope ps(t, 1, s);
     HIP_TRY(launch_layernorm(w.x, D, t->lnpre_g, t->lnpre_b, (int64_t)B * N, D, nullptr, nullptr, w.x, s));
   }
-  rc = run_blocks(t, w.x, B, N, 0, w, nullptr, nullptr, s);
+  rc = t->fp8 ? run_blocks_fp8(t, w.x, B, N, w, s) : run_blocks(t, w.x, B, N, 0, w, nullptr, nullptr, s);
   if (rc) return rc;
   {
     ProfScope ps(t, 7, s);

@@ -127,7 +127,9 @@ class TextTower(_Tower):
     _TOP = ("token_embedding.weight", "positional_embedding", "ln_final.weight", "ln_final.bias", "text_projection")
 
     def __init__(self, cfg: ClipDims, state_dict, device="cuda", precision: str = "bf16"):
-        super().__init__(cfg, cfg.text, state_dict, device, precision)
+        # "fp8" is an image-tower precision (frozen weights, no backward: BASELINE.json configs[4]); the text
+        # tower carries the prompt gradients and stays bf16 beside it
+        super().__init__(cfg, cfg.text, state_dict, device, "bf16" if precision == "fp8" else precision)
 
     def _wanted(self, key):
         if key.startswith("transformer.resblocks.") or key in self._TOP:

@@ -9,7 +9,9 @@ under open_clip's names so `state_dict()` / `load_state_dict()` keep the referen
 (`clip.model.*`, reference test_cross_domain.py:43-61).
 
 Extra keyword-only knobs (defaults keep behaviour):
-  precision       "bf16" (fast) | "bf16x3" (split-bf16, ~fp32 accuracy: the parity mode)
+  precision       "bf16" (fast) | "bf16x3" (split-bf16, ~fp32 accuracy: the parity mode) |
+                  "fp8" (image tower block GEMMs on MXFP8 MFMA, text tower bf16; a throughput mode:
+                  ~4 % error per GEMM)
   attn_semantics  "intended": the text hook yields the head-mean softmax map [n,T,T] that the
                   reference documents (clip_wrapper.py:35-36);
                   "literal": what the reference's hook really captures -- `output[0]` of

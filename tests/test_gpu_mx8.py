@@ -97,3 +97,78 @@ def test_gemm_gelu_requantised_epilogue(eng, act):
     assert torch.equal(mx8_ref.scales_from_kstep_major(osc.cpu(), M), s_ref) or float((mx8_ref.scales_from_kstep_major(osc.cpu(), M) != s_ref).float().mean()) < 1e-3
     assert float((got - ref).norm() / ref.norm()) < 5e-3
     assert float((got - y).norm() / y.norm()) < 4e-2  # MXFP8 rounding of the activation itself
+
+
+# ---- the fp8 precision of the image tower ---------------------------------------------------------
+def _one_block_vision(eng, d, heads, mlp, seed, precision):
+    from tap_clip_amd import configs, synth
+    cfg = configs.ClipDims("blk8", 64, 32, 16, configs.TowerDims(d, 1, heads, mlp), configs.TowerDims(128, 1, 2, 256), vocab=16, ctx=8)
+    sd = {}
+    synth._tower(sd, "visual.transformer.", d, 1, mlp, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    sd["visual.conv1.weight"] = torch.randn(d, 3, 16, 16, generator=g) * 0.03
+    sd["visual.class_embedding"] = torch.randn(d, generator=g) * 0.3
+    sd["visual.positional_embedding"] = torch.randn(5, d, generator=g) * 0.3
+    for k in ("ln_pre", "ln_post"):
+        sd[f"visual.{k}.weight"] = 1.0 + 0.1 * torch.randn(d, generator=g)
+        sd[f"visual.{k}.bias"] = 0.05 * torch.randn(d, generator=g)
+    sd["visual.proj"] = torch.randn(d, 64, generator=g) * d ** -0.5
+    return cfg, sd, eng.VisionTower(cfg, sd, DEV, precision)
+
+
+@pytest.mark.parametrize("d,heads,mlp", [(768, 12, 3072), (1024, 16, 4096)])
+def test_fp8_block_vs_mx8_emulation(eng, d, heads, mlp):
+    """One residual block at the real widths (ViT-B/16 and ViT-L/14), 32 x 32 images (5 tokens), batch 300 so that
+    the GEMMs see several row tiles and a ragged last one: the fp8 tower against the oracle with MXFP8 rounding at
+    the same operand points (emulate="mx8"), and against the fp32 oracle."""
+    from oracle import clip_ref
+    cfg, sd, tower = _one_block_vision(eng, d, heads, mlp, 5, "fp8")
+    from tap_clip_amd import synth
+    images = synth.make_images(300, cfg, 7)
+    got = tower.encode_image(images.to(DEV)).cpu()
+    ocfg = clip_ref.ClipDims("blk8", 64, 32, 16, clip_ref.TowerDims(d, 1, heads, mlp), clip_ref.TowerDims(128, 1, 2, 256), vocab=16, ctx=8)
+    with torch.no_grad():
+        emu = clip_ref.encode_image(images, sd, ocfg, emulate="mx8")
+        ref = clip_ref.encode_image(images, sd, ocfg)
+    e_emu = float((got - emu).norm() / emu.norm())
+    e_ref = float((got - ref).norm() / ref.norm())
+    print(f"[fp8 block d={d}] vs mx8 emulation rel_l2 {e_emu:.3e}; vs fp32 oracle rel_l2 {e_ref:.3e}")
+    # The operand bytes agree except where a value sits within the kernels' bf16-level differences (patch embed,
+    # GELU fit, accumulation order: ~1e-3) of an e4m3 rounding boundary; such an element moves by a whole e4m3 step
+    # (6-12 %), so ~1-2 % flipped elements leave ~1 % rel_l2 (measured 1.1e-2), a quarter of the format's own error.
+    # A misplaced scale or block shows up as tens of percent.
+    assert e_emu < 2e-2 and e_emu < 0.5 * e_ref
+    assert e_ref < 5e-2  # MXFP8: 3 mantissa bits per operand element
+    assert torch.isfinite(got).all()
+
+
+def test_fp8_encode_image_vitb16(eng):
+    """Full ViT-B/16 image tower in fp8 against the fp32 golden embeddings and the bf16 path: what the throughput
+    mode costs in accuracy (reported, bounded loosely), plus determinism and ragged batches."""
+    import numpy as np
+    from tap_clip_amd import configs, synth
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "image_tower_ViT-B-16.npz"))
+    cfg = configs.get_config("ViT-B-16")
+    sd = synth.make_state_dict(cfg, seed=int(g["seed_weights"]), text=False)
+    images = synth.make_images(int(g["batch"]), cfg, int(g["seed_images"]))
+    ref = torch.from_numpy(g["embeddings"])
+    tower = eng.VisionTower(cfg, sd, DEV, "fp8")
+    a = tower.encode_image(images.to(DEV)).cpu()
+    b = tower.encode_image(images.to(DEV)).cpu()
+    assert torch.equal(a, b), "same input twice must be bit-identical"
+    rel = float((a - ref).norm() / ref.norm())
+    cos = torch.nn.functional.cosine_similarity(a, ref, dim=-1)
+    print(f"[fp8 ViT-B/16] vs fp32 golden: rel_l2 {rel:.3e}, cosine min {float(cos.min()):.5f} mean {float(cos.mean()):.5f}")
+    assert rel < 0.15 and float(cos.min()) > 0.99
+    one = tower.encode_image(images[:1].to(DEV)).cpu()   # M = 197: a single ragged row tile
+    assert float((one - a[:1]).norm() / a[:1].norm()) < 1e-6
+
+
+def test_fp8_text_tower_stays_bf16(eng):
+    from tap_clip_amd import configs, synth
+    cfg = configs.get_config("tiny")
+    sd = synth.make_state_dict(cfg, seed=2)
+    t = eng.TextTower(cfg, sd, DEV, "fp8")
+    assert t.precision == "bf16"
+    with pytest.raises(ValueError):
+        eng.VisionTower(cfg, sd, DEV, "fp8")  # width 128: the MXFP8 GEMM needs width % 256 == 0
