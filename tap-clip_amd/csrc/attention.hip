@@ -14,7 +14,9 @@
 //   O^T[d, q] = V^T . P^T   (A = V^T via ds_read_b64_tr_b16 transposed LDS reads, B = P^T = the S^T
 //        registers themselves, packed to bf16: element jj of k-step s2 is key 16*(2*s2 + (jj>>2)) + 4*g
 //        + (jj&3); the V^T fragment is read with the same key order)
-//     -> lane holds 4 consecutive d of one query: 8-byte stores.
+//     Which d feeds which MFMA row is only the transposed read's address: product dt takes the column quads
+//     {16 pp + 4 dt .. + 3, pp = 0..3}, so lane (q, g) ends up with d = 16 g + 4 dt + e -- 16 CONSECUTIVE d
+//     of its query over the four products: 32-byte bf16 / 16-byte MXFP8 stores, 128 / 64 B per row.
 // bf16x3 (SPLIT): K, V, Q and P are hi/lo pairs and every product is three MFMAs.
 #include <cstdlib>
 
@@ -34,31 +36,56 @@ __device__ __forceinline__ bf16x8_t tr_pair(const uint8_t* base0, const uint8_t*
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
-// MXFP8 store of one query row's head slice: lane (r, g) holds O[q][16 dt + 4 g + e] * 1/sum for dt = 0..3.  The
-// head's 64 columns are two 32-blocks (dt 0,1 | dt 2,3), each spread over the row's four g-lanes.  Called by all
-// lanes (the shuffles need them); `valid` masks the stores.
+// Stores of one query row's head slice: lane (r, g) holds O[q][16 g + 4 dt + e] / sum for dt = 0..3, i.e. 16
+// consecutive columns.  bf16: 32 bytes per lane.
+template <bool SPLIT>
+__device__ __forceinline__ void store_o_bf16(const AttnArgs& a, const f32x4_t (&oc)[4], float inv, int64_t row, int head, int g) {
+  const int64_t off = row * a.D + head * 64 + 16 * g;
+  uint32_t wh[8], wl[8];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    if (SPLIT) {
+      bf16_t h[4], l[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split_bf(oc[dt][e] * inv, h[e], l[e]);
+      wh[2 * dt] = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+      wh[2 * dt + 1] = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+      wl[2 * dt] = (uint32_t)l[0] | ((uint32_t)l[1] << 16);
+      wl[2 * dt + 1] = (uint32_t)l[2] | ((uint32_t)l[3] << 16);
+    } else {
+      wh[2 * dt] = pack_bf2(oc[dt][0] * inv, oc[dt][1] * inv);
+      wh[2 * dt + 1] = pack_bf2(oc[dt][2] * inv, oc[dt][3] * inv);
+    }
+  }
+  uint4* dh = reinterpret_cast<uint4*>(a.out_hi + off);
+  dh[0] = make_uint4(wh[0], wh[1], wh[2], wh[3]);
+  dh[1] = make_uint4(wh[4], wh[5], wh[6], wh[7]);
+  if (SPLIT) {
+    uint4* dl = reinterpret_cast<uint4*>(a.out_lo + off);
+    dl[0] = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+    dl[1] = make_uint4(wl[4], wl[5], wl[6], wl[7]);
+  }
+}
+// MXFP8: the head's 64 columns are two 32-blocks, block b held by the lanes g = 2 b, 2 b + 1 of the row.  Called by
+// all lanes (the shuffle needs them); `valid` masks the stores.
 __device__ __forceinline__ void store_o_mx8(const AttnArgs& a, const f32x4_t (&oc)[4], float inv, int64_t row, int head, int g,
                                             bool valid) {
-  float am[2] = {0.f, 0.f};
+  float am = 0.f;
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) am[dt >> 1] = fmaxf(am[dt >> 1], fabsf(oc[dt][e] * inv));
-  uint32_t byte[2];
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    am[b] = fmaxf(am[b], __shfl_xor(am[b], 16, 64));
-    am[b] = fmaxf(am[b], __shfl_xor(am[b], 32, 64));
-    byte[b] = mx8_scale_byte(am[b]);
-  }
+    for (int e = 0; e < 4; ++e) am = fmaxf(am, fabsf(oc[dt][e] * inv));
+  am = fmaxf(am, __shfl_xor(am, 16, 64));
+  const uint32_t byte = mx8_scale_byte(am);
   if (!valid) return;
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) {
-    const float is = mx8_inv_scale(byte[dt >> 1]);
-    *reinterpret_cast<uint32_t*>(a.out_q + row * a.D + head * 64 + 16 * dt + 4 * g) =
-        mx8_pack4(oc[dt][0] * inv, oc[dt][1] * inv, oc[dt][2] * inv, oc[dt][3] * inv, is);
-  }
-  if (g == 0) *reinterpret_cast<uint16_t*>(a.out_q_scale + ((size_t)head * a.out_m_pad + row) * 2) = (uint16_t)(byte[0] | (byte[1] << 8));
+  const float is = mx8_inv_scale(byte);
+  uint4 pk;
+  pk.x = mx8_pack4(oc[0][0] * inv, oc[0][1] * inv, oc[0][2] * inv, oc[0][3] * inv, is);
+  pk.y = mx8_pack4(oc[1][0] * inv, oc[1][1] * inv, oc[1][2] * inv, oc[1][3] * inv, is);
+  pk.z = mx8_pack4(oc[2][0] * inv, oc[2][1] * inv, oc[2][2] * inv, oc[2][3] * inv, is);
+  pk.w = mx8_pack4(oc[3][0] * inv, oc[3][1] * inv, oc[3][2] * inv, oc[3][3] * inv, is);
+  *reinterpret_cast<uint4*>(a.out_q + row * a.D + head * 64 + 16 * g) = pk;
+  if ((g & 1) == 0) a.out_q_scale[((size_t)head * a.out_m_pad + row) * 2 + (g >> 1)] = (uint8_t)byte;
 }
 
 template <int NKT, bool SPLIT>
@@ -128,12 +155,15 @@ __global__ __launch_bounds__(512) void attn_kernel(AttnArgs a) {
       const int key = c >> 3, kc = c & 7;
       if (key >= KEYS) continue;  // KEYS * 8 need not be a multiple of 512
       const int ko = key * 128 + ((kc ^ (key & 7)) << 4);
-      const int vo = key * 128 + (((((kc >> 1) ^ (key >> 1)) & 3) << 1 | (kc & 1)) << 4);  // 32-B block ^ ((key>>1)&3): conflict-free tr reads
+      // V image: 8-byte quad u of a 32-B block sits at quad u ^ ((key >> 1) & 3): the transposed reads below
+      // (one quad index, all four blocks, 8 keys per 32-lane group) are then conflict-free
+      const int vs = (key >> 1) & 3;
+      const int vo = key * 128 + ((kc >> 1) << 5) + (((kc & 1) ^ (vs >> 1)) << 4);
       *reinterpret_cast<uint4*>(Kh + ko) = kv[it];
-      *reinterpret_cast<uint4*>(Vh + vo) = vv[it];
+      *reinterpret_cast<uint4*>(Vh + vo) = (vs & 1) ? make_uint4(vv[it].z, vv[it].w, vv[it].x, vv[it].y) : vv[it];
       if (SPLIT) {
         *reinterpret_cast<uint4*>(Kl + ko) = kvl[it];
-        *reinterpret_cast<uint4*>(Vl + vo) = vvl[it];
+        *reinterpret_cast<uint4*>(Vl + vo) = (vs & 1) ? make_uint4(vvl[it].z, vvl[it].w, vvl[it].x, vvl[it].y) : vvl[it];
       }
     }
   }
@@ -237,7 +267,7 @@ __global__ __launch_bounds__(512) void attn_kernel(AttnArgs a) {
       const int sw = (key0 >> 1) & 3;  // == (key1 >> 1) & 3: the keys differ by 16
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const int coff = ((dt ^ sw) << 5) + 8 * pp;  // swizzled 32-B block of the 16 d's, 8 B per lane
+        const int coff = (pp << 5) + ((dt ^ sw) << 3);  // block pp, swizzled quad dt: columns 16 pp + 4 dt .. + 3
         const bf16x8_t vf = tr_pair(Vh + key0 * 128 + coff, Vh + key1 * 128 + coff);
         oc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, ph, oc[dt], 0, 0, 0);
         if (SPLIT) {
@@ -248,31 +278,9 @@ __global__ __launch_bounds__(512) void attn_kernel(AttnArgs a) {
       }
     }
 
-    // ---- store: lane holds O[q = qi][d = 16*dt + 4*g + e]
-    if (!SPLIT && a.out_q != nullptr) {  // (kernel-uniform)
-      store_o_mx8(a, oc, inv, row0 + qi, head, g, qi < T);
-    } else if (qi < T) {
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const int64_t off = (row0 + qi) * D + head * 64 + 16 * dt + 4 * g;
-        bf16_t h[4], l[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (SPLIT) split_bf(oc[dt][e] * inv, h[e], l[e]);
-          else h[e] = f2bf(oc[dt][e] * inv);
-        }
-        uint2 phk;
-        phk.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
-        phk.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
-        *reinterpret_cast<uint2*>(a.out_hi + off) = phk;
-        if (SPLIT) {
-          uint2 plk;
-          plk.x = (uint32_t)l[0] | ((uint32_t)l[1] << 16);
-          plk.y = (uint32_t)l[2] | ((uint32_t)l[3] << 16);
-          *reinterpret_cast<uint2*>(a.out_lo + off) = plk;
-        }
-      }
-    }
+    // ---- store: lane holds O[q = qi][d = 16*g + 4*dt + e]
+    if (!SPLIT && a.out_q != nullptr) store_o_mx8(a, oc, inv, row0 + qi, head, g, qi < T);  // (kernel-uniform branch)
+    else if (qi < T) store_o_bf16<SPLIT>(a, oc, inv, row0 + qi, head, g);
   }
 }
 
@@ -344,7 +352,12 @@ __global__ __launch_bounds__(512) void attn_flash_kernel(AttnArgs a) {
         }
       }
       const int ko = kk * 128 + ((kc ^ (kk & 7)) << 4);
-      const int vo = kk * 128 + (((((kc >> 1) ^ (kk >> 1)) & 3) << 1 | (kc & 1)) << 4);
+      const int vs = (kk >> 1) & 3;  // quad swizzle of the V image, as in attn_kernel
+      const int vo = kk * 128 + ((kc >> 1) << 5) + (((kc & 1) ^ (vs >> 1)) << 4);
+      if (vs & 1) {
+        vv = make_uint4(vv.z, vv.w, vv.x, vv.y);
+        vvl = make_uint4(vvl.z, vvl.w, vvl.x, vvl.y);
+      }
       *reinterpret_cast<uint4*>(Kh + ko) = kv;
       *reinterpret_cast<uint4*>(Vh + vo) = vv;
       if (SPLIT) {
@@ -432,7 +445,7 @@ __global__ __launch_bounds__(512) void attn_flash_kernel(AttnArgs a) {
         const int sw = (key0 >> 1) & 3;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          const int coff = ((dt ^ sw) << 5) + 8 * pp;
+          const int coff = (pp << 5) + ((dt ^ sw) << 3);
           const bf16x8_t vf = tr_pair(Vh + key0 * 128 + coff, Vh + key1 * 128 + coff);
           oc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, ph, oc[t][dt], 0, 0, 0);
           if (SPLIT) {
@@ -453,30 +466,8 @@ __global__ __launch_bounds__(512) void attn_flash_kernel(AttnArgs a) {
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
-    if (!SPLIT && a.out_q != nullptr) {
-      store_o_mx8(a, oc[t], inv, row0 + qi, head, g, qi < T);
-    } else if (qi < T) {
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const int64_t off = (row0 + qi) * D + head * 64 + 16 * dt + 4 * g;
-        bf16_t h[4], lo4[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (SPLIT) split_bf(oc[t][dt][e] * inv, h[e], lo4[e]);
-          else h[e] = f2bf(oc[t][dt][e] * inv);
-        }
-        uint2 phk;
-        phk.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
-        phk.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
-        *reinterpret_cast<uint2*>(a.out_hi + off) = phk;
-        if (SPLIT) {
-          uint2 plk;
-          plk.x = (uint32_t)lo4[0] | ((uint32_t)lo4[1] << 16);
-          plk.y = (uint32_t)lo4[2] | ((uint32_t)lo4[3] << 16);
-          *reinterpret_cast<uint2*>(a.out_lo + off) = plk;
-        }
-      }
-    }
+    if (!SPLIT && a.out_q != nullptr) store_o_mx8(a, oc[t], inv, row0 + qi, head, g, qi < T);
+    else if (qi < T) store_o_bf16<SPLIT>(a, oc[t], inv, row0 + qi, head, g);
   }
 }
 
