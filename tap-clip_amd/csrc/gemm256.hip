@@ -570,7 +570,7 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
     n_cu = prop.multiProcessorCount / 8 * 8;
     if (n_cu < 8) n_cu = 8;
   }
-  const int64_t nwg = tiles < n_cu ? (tiles + 7) / 8 * 8 : n_cu;
+  int64_t nwg = tiles < n_cu ? (tiles + 7) / 8 * 8 : n_cu;
   GemmArgs b = a;
   static const int gm_env = [] {
     const char* e = getenv("TAPCLIP_GROUP_M");
@@ -582,11 +582,12 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
   // workgroups over 1/S of K into fp32 partial tiles, summed by splitk_fixup_kernel.
   b.split_parts = 0;
   static const bool no_tail_split = getenv("TAPCLIP_NO_TAIL_SPLIT") != nullptr;
-  if (!SPLIT && BN == 256 && (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16) && a.split_ws != nullptr && !no_tail_split &&
-      tiles > n_cu) {
+  // The same machinery covers a GEMM with fewer tiles than half the CUs (the text tower's c_proj: 96 tiles of
+  // K = 2048 on 256 CUs, 40 us): every tile is K-split (split_from = 0) and the grid grows to tiles x parts.
+  if (!SPLIT && (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16) && a.split_ws != nullptr && !no_tail_split) {
     const int64_t full = tiles / n_cu, rem = tiles - full * n_cu;
     const int ks = a.K / BKS;
-    if (rem > 0 && rem * 2 <= n_cu) {
+    if (rem > 0 && rem * 2 <= n_cu && (full == 0 || BN == 256)) {
       int parts = (int)(n_cu / rem);
       // a part shorter than ~16 K steps is all pipeline fill and drain: it costs more than the idle CUs
       static const int min_ks = [] {
@@ -597,6 +598,7 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
       if (parts >= 2 && rem * parts <= SPLIT_WS_TILES) {
         b.split_from = (int)(full * n_cu);
         b.split_parts = parts;
+        if (full == 0) nwg = (rem * parts + 7) / 8 * 8;
       }
     }
   }

@@ -138,6 +138,20 @@ def test_block_vs_golden(eng, tag, precision):
         assert rel_l2(r["hidden"].cpu(), y) < TOL_EMU
 
 
+def test_block_small_gemm_split_k(eng):
+    """Text-tower dims at M = 30 x 77 = 2310 rows: c_proj (N = 512, K = 2048) has 40 tiles for 256 CUs, so the
+    persistent GEMM K-splits every tile (gemm256.hip launch_t, split_from = 0) and the fix-up kernel sums the parts."""
+    tower, sd = _one_layer_tower(eng, 512, 8, 2048, 17, "bf16")
+    x = synth.normal([30, 77, 512], 18, "block.split.x")
+    got = tower.forward(x.to(DEV))["hidden"].cpu()
+    with torch.no_grad():
+        emu, _ = clip_ref.block_forward(x, sd, "transformer.resblocks.0.", 8, emulate="bf16")
+        ref, _ = clip_ref.block_forward(x, sd, "transformer.resblocks.0.", 8)
+    _report("block split-K bf16 vs emulated", got, emu)
+    assert rel_l2(got, emu) < TOL_EMU
+    assert rel_max(got, ref) < TOL_BF16
+
+
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("causal", [False, True])
 def test_long_sequence_flash_attention(eng, precision, causal):
