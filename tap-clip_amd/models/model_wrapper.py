@@ -70,7 +70,7 @@ class _LogitsFn(torch.autograd.Function):
 class FullModel(nn.Module):
     def __init__(self, class_names, clip_wrapper, prompt_len=5, attr_lambda=1.0, stab_lambda=0.1,
                  adjustor_method='scale', class_specific=False, *, collapse_text: bool = True,
-                 gather_images: bool = False):
+                 gather_images: bool = False, overlap_towers: bool = True):
         super().__init__()
         self.clip = clip_wrapper
         self.class_names = class_names
@@ -85,6 +85,11 @@ class FullModel(nn.Module):
         self.logit_scale = nn.Parameter(torch.ones([]) * math.log(1 / 0.07))
         self.collapse_text = collapse_text
         self.gather_images = gather_images
+        # The image tower does not depend on the text side: it is launched on a second HIP stream so that its
+        # chip-filling kernels run beside the text tower's small grids (65 x 93 rows: 96-192 workgroups per GEMM
+        # on 256 CUs) instead of after them.
+        self.overlap_towers = overlap_towers
+        self._side_stream = None
         # a checkpoint that carries other `clip.model.*` weights re-packs the towers (clip_wrapper.py here);
         # the frozen class-token embeddings derived from them are then re-computed as well
         self._clip_version = getattr(clip_wrapper, "weights_version", 0)
@@ -96,6 +101,29 @@ class FullModel(nn.Module):
         if v != module._clip_version:
             module._clip_version = v
             module.prompt_learner.refresh_token_bank()
+
+    # ---- image side ----------------------------------------------------------------------------
+    def _image_features_begin(self, images: torch.Tensor):
+        """Launch `encode_image` (reference model_wrapper.py:40-41); returns (features, stream to join)."""
+        vision = self.clip._vision
+        if not (self.overlap_towers and images.is_cuda):
+            return vision.encode_image(images, normalize=True), None
+        dev = images.device
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=dev)
+        side = self._side_stream
+        side.wait_stream(torch.cuda.current_stream(dev))  # the images were produced on the caller's stream
+        with torch.cuda.stream(side):
+            feat = vision.encode_image(images, normalize=True)
+        return feat, side
+
+    @staticmethod
+    def _image_features_end(feat: torch.Tensor, side) -> torch.Tensor:
+        if side is not None:
+            main = torch.cuda.current_stream(feat.device)
+            main.wait_stream(side)
+            feat.record_stream(main)
+        return feat
 
     # ---- text side -----------------------------------------------------------------------------
     def text_features(self) -> torch.Tensor:
@@ -155,10 +183,7 @@ class FullModel(nn.Module):
         reference's hook detaches it (clip_wrapper.py:36)."""
         pl, clip = self.prompt_learner, self.clip
         with torch.no_grad():
-            image_feat = clip._vision.encode_image(images, normalize=True)
-            if self.gather_images:
-                from ..dist import all_gather_rows
-                image_feat = all_gather_rows(image_feat)
+            image_feat, side = self._image_features_begin(images)
             ctx_c, tok = pl.stacked_context().detach(), pl.stacked_tokens()
             clip.reset()
             clip.model.transformer(engine.build_prompts(ctx_c, tok))
@@ -169,6 +194,11 @@ class FullModel(nn.Module):
         ctx = pl.stacked_context()                                   # differentiable w.r.t. every context_bank entry
         adjusted = torch.cat([self.prompt_adjustor(ctx, attribution), tok], dim=1)
         text_feat = _TextTowerFn.apply(adjusted, clip)
+        with torch.no_grad():
+            image_feat = self._image_features_end(image_feat, side)
+            if self.gather_images:
+                from ..dist import all_gather_rows
+                image_feat = all_gather_rows(image_feat)
         logits = _LogitsFn.apply(image_feat, text_feat, self.logit_scale)
         self.last_attribution = attribution
         outputs = {"logits": logits}
@@ -185,11 +215,12 @@ class FullModel(nn.Module):
             if not self.collapse_text:
                 logits = self._forward_literal(images)
             else:
-                image_feat = self.clip._vision.encode_image(images, normalize=True)      # model_wrapper.py:40-41
+                image_feat, side = self._image_features_begin(images)                     # model_wrapper.py:40-41
+                text_feat = self.text_features()
+                image_feat = self._image_features_end(image_feat, side)
                 if self.gather_images:
                     from ..dist import all_gather_rows
                     image_feat = all_gather_rows(image_feat)
-                text_feat = self.text_features()
                 logits = engine.logits(image_feat, text_feat, float(self.logit_scale.exp()))  # :79,83
             outputs = {"logits": logits}
             if labels is not None:
