@@ -81,9 +81,13 @@ hipError_t launch_layernorm(const float* x, int64_t ldx, const float* gamma, con
 hipError_t launch_add_layernorm(float* x, const bf16_t* delta_hi, const bf16_t* delta_lo, const float* gamma,
                                 const float* beta, int64_t rows, int32_t d, bf16_t* out_hi, bf16_t* out_lo,
                                 hipStream_t s);
-// LayerNorm (optionally after x += delta) with MXFP8 output: out_q [rows, d] e4m3 + out_sc [d/64][rows_pad][2]
-hipError_t launch_layernorm_mx8(float* x, const bf16_t* delta_hi, const float* gamma, const float* beta, int64_t rows, int32_t d,
-                                uint8_t* out_q, uint8_t* out_sc, int64_t rows_pad, hipStream_t s);
+// add: 1 = x += d1 (written back); 2 = LayerNorm(x + d1), x NOT written back; 3 = x += d1 + d2 (written back)
+hipError_t launch_add_layernorm_ex(int add, float* x, const bf16_t* d1_hi, const bf16_t* d1_lo, const bf16_t* d2_hi,
+                                   const bf16_t* d2_lo, const float* gamma, const float* beta, int64_t rows, int32_t d,
+                                   bf16_t* out_hi, bf16_t* out_lo, hipStream_t s);
+// LayerNorm with MXFP8 output: out_q [rows, d] e4m3 + out_sc [d/64][rows_pad][2]; add = 0 (none) or as above
+hipError_t launch_layernorm_mx8(int add, float* x, const bf16_t* d1_hi, const bf16_t* d2_hi, const float* gamma, const float* beta,
+                                int64_t rows, int32_t d, uint8_t* out_q, uint8_t* out_sc, int64_t rows_pad, hipStream_t s);
 // x[i] += delta_hi[i] (+ delta_lo[i])
 hipError_t launch_add_delta(float* x, const bf16_t* delta_hi, const bf16_t* delta_lo, int64_t n, hipStream_t s);
 

@@ -9,11 +9,15 @@ namespace tapclip {
 namespace {
 
 // MODE 0: bf16 hi   1: bf16 hi + lo   2: fp32   3: MXFP8 (e4m3 bytes + one e8m0 scale per 32 columns; vector kernel only)
-// ADD: the row first receives the pending residual branch, x += delta (bf16 hi [+ lo], the output of the
-// preceding out_proj / c_proj GEMM), and the updated fp32 row is written back before it is normalised.
-template <int MODE, int NV, bool ADD>  // NV float4 per lane: d = 256 * NV
+// ADD: the row first receives pending residual branches (bf16 hi [+ lo], outputs of the preceding out_proj /
+// c_proj GEMMs) before it is normalised:
+//   1  x += d1, written back            2  x + d1 normalised, x NOT written back (LN2: saves 4 of 12 B/element)
+//   3  x += d1 + d2, written back       (the next block's LN1 then folds both branches: 14 B/element; a block's two
+//                                        LayerNorms move 22 B/element instead of 24)
+template <int MODE, int NV, int ADD>  // NV float4 per lane: d = 256 * NV
 __global__ __launch_bounds__(256) void ln_vec_kernel(float* __restrict__ x, int64_t ldx,
                                                      const bf16_t* __restrict__ d_hi, const bf16_t* __restrict__ d_lo,
+                                                     const bf16_t* __restrict__ e_hi, const bf16_t* __restrict__ e_lo,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, int64_t rows, int d,
                                                      bf16_t* out_hi, bf16_t* out_lo, float* out_f32,
@@ -29,15 +33,18 @@ __global__ __launch_bounds__(256) void ln_vec_kernel(float* __restrict__ x, int6
     const int c = 4 * lane + 256 * j;
     v[j] = *reinterpret_cast<const float4*>(xr + c);
     if (ADD) {
-      const uint2 h = *reinterpret_cast<const uint2*>(d_hi + row * d + c);
-      v[j].x += bf2f((bf16_t)(h.x & 0xFFFF)); v[j].y += bf2f((bf16_t)(h.x >> 16));
-      v[j].z += bf2f((bf16_t)(h.y & 0xFFFF)); v[j].w += bf2f((bf16_t)(h.y >> 16));
-      if (d_lo != nullptr) {
-        const uint2 l = *reinterpret_cast<const uint2*>(d_lo + row * d + c);
-        v[j].x += bf2f((bf16_t)(l.x & 0xFFFF)); v[j].y += bf2f((bf16_t)(l.x >> 16));
-        v[j].z += bf2f((bf16_t)(l.y & 0xFFFF)); v[j].w += bf2f((bf16_t)(l.y >> 16));
+      auto add4 = [&](const bf16_t* p) {
+        const uint2 h = *reinterpret_cast<const uint2*>(p + row * d + c);
+        v[j].x += bf2f((bf16_t)(h.x & 0xFFFF)); v[j].y += bf2f((bf16_t)(h.x >> 16));
+        v[j].z += bf2f((bf16_t)(h.y & 0xFFFF)); v[j].w += bf2f((bf16_t)(h.y >> 16));
+      };
+      add4(d_hi);
+      if (d_lo != nullptr) add4(d_lo);
+      if (ADD == 3) {
+        add4(e_hi);
+        if (e_lo != nullptr) add4(e_lo);
       }
-      *reinterpret_cast<float4*>(xr + c) = v[j];
+      if (ADD != 2) *reinterpret_cast<float4*>(xr + c) = v[j];
     }
     s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
   }
@@ -88,10 +95,11 @@ __global__ __launch_bounds__(256) void ln_vec_kernel(float* __restrict__ x, int6
   }
 }
 
-// generic widths (d % 64 == 0, small test models): scalar, two passes over an L1-resident row
-template <int MODE, bool ADD>
+// generic widths (d % 64 == 0, small test models): scalar, three passes over an L1-resident row
+template <int MODE, int ADD>
 __global__ __launch_bounds__(256) void ln_generic_kernel(float* __restrict__ x, int64_t ldx,
                                                          const bf16_t* __restrict__ d_hi, const bf16_t* __restrict__ d_lo,
+                                                         const bf16_t* __restrict__ e_hi, const bf16_t* __restrict__ e_lo,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, int64_t rows, int d,
                                                          bf16_t* out_hi, bf16_t* out_lo, float* out_f32) {
@@ -99,26 +107,35 @@ __global__ __launch_bounds__(256) void ln_generic_kernel(float* __restrict__ x, 
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   float* xr = x + row * ldx;
-  if (ADD) {  // each lane updates (and later re-reads) only its own elements
-    for (int c = lane; c < d; c += 64) {
-      float t = xr[c] + bf2f(d_hi[row * d + c]);
+  auto val = [&](int c) {  // the row element with its pending branches (same order of additions as ln_vec_kernel)
+    float t = xr[c];
+    if (ADD) {
+      t += bf2f(d_hi[row * d + c]);
       if (d_lo != nullptr) t += bf2f(d_lo[row * d + c]);
-      xr[c] = t;
+      if (ADD == 3) {
+        t += bf2f(e_hi[row * d + c]);
+        if (e_lo != nullptr) t += bf2f(e_lo[row * d + c]);
+      }
     }
+    return t;
+  };
+  if (ADD == 1 || ADD == 3) {  // each lane updates (and later re-reads) only its own elements
+    for (int c = lane; c < d; c += 64) xr[c] = val(c);
   }
+  auto cur = [&](int c) { return ADD == 2 ? val(c) : xr[c]; };
   float s = 0.f;
-  for (int c = lane; c < d; c += 64) s += xr[c];
+  for (int c = lane; c < d; c += 64) s += cur(c);
   const float mean = wave_sum(s) / (float)d;
   float ss = 0.f;
   for (int c = lane; c < d; c += 64) {
-    const float t = xr[c] - mean;
+    const float t = cur(c) - mean;
     ss += t * t;
   }
   const float rstd = rsqrtf(wave_sum(ss) / (float)d + 1e-5f);
   // every lane has finished READING the row (the reductions above are wave-wide) before any write,
   // so out_f32 may alias x
   for (int c = lane; c < d; c += 64) {
-    const float y = (xr[c] - mean) * rstd * gamma[c] + beta[c];
+    const float y = (cur(c) - mean) * rstd * gamma[c] + beta[c];
     if (MODE == 2) {
       out_f32[row * d + c] = y;
     } else if (MODE == 1) {
@@ -132,23 +149,36 @@ __global__ __launch_bounds__(256) void ln_generic_kernel(float* __restrict__ x, 
   }
 }
 
-template <int MODE, bool ADD>
-hipError_t launch_mode(float* x, int64_t ldx, const bf16_t* dh, const bf16_t* dl, const float* gamma, const float* beta,
-                       int64_t rows, int32_t d, bf16_t* hi, bf16_t* lo, float* f32, hipStream_t s, uint8_t* q = nullptr,
+template <int MODE, int ADD>
+hipError_t launch_mode(float* x, int64_t ldx, const bf16_t* dh, const bf16_t* dl, const bf16_t* eh, const bf16_t* el, const float* gamma,
+                       const float* beta, int64_t rows, int32_t d, bf16_t* hi, bf16_t* lo, float* f32, hipStream_t s, uint8_t* q = nullptr,
                        uint8_t* qs = nullptr, int64_t rows_pad = 0) {
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   if (d % 256 == 0 && d / 256 <= 4 && ldx % 4 == 0) {
     switch (d / 256) {
-      case 1: hipLaunchKernelGGL((ln_vec_kernel<MODE, 1, ADD>), grid, block, 0, s, x, ldx, dh, dl, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
-      case 2: hipLaunchKernelGGL((ln_vec_kernel<MODE, 2, ADD>), grid, block, 0, s, x, ldx, dh, dl, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
-      case 3: hipLaunchKernelGGL((ln_vec_kernel<MODE, 3, ADD>), grid, block, 0, s, x, ldx, dh, dl, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
-      default: hipLaunchKernelGGL((ln_vec_kernel<MODE, 4, ADD>), grid, block, 0, s, x, ldx, dh, dl, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+      case 1: hipLaunchKernelGGL((ln_vec_kernel<MODE, 1, ADD>), grid, block, 0, s, x, ldx, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+      case 2: hipLaunchKernelGGL((ln_vec_kernel<MODE, 2, ADD>), grid, block, 0, s, x, ldx, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+      case 3: hipLaunchKernelGGL((ln_vec_kernel<MODE, 3, ADD>), grid, block, 0, s, x, ldx, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+      default: hipLaunchKernelGGL((ln_vec_kernel<MODE, 4, ADD>), grid, block, 0, s, x, ldx, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
     }
   } else {
     if constexpr (MODE == 3) return hipErrorInvalidValue;  // MXFP8 output: widths 256 .. 1024 only
-    else hipLaunchKernelGGL((ln_generic_kernel<MODE, ADD>), grid, block, 0, s, x, ldx, dh, dl, gamma, beta, rows, d, hi, lo, f32);
+    else hipLaunchKernelGGL((ln_generic_kernel<MODE, ADD>), grid, block, 0, s, x, ldx, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32);
   }
   return hipGetLastError();
+}
+
+template <int MODE>
+hipError_t launch_add_mode(int add, float* x, const bf16_t* dh, const bf16_t* dl, const bf16_t* eh, const bf16_t* el, const float* gamma,
+                           const float* beta, int64_t rows, int32_t d, bf16_t* hi, bf16_t* lo, hipStream_t s, uint8_t* q = nullptr,
+                           uint8_t* qs = nullptr, int64_t rows_pad = 0) {
+  switch (add) {
+    case 0: return launch_mode<MODE, 0>(x, d, nullptr, nullptr, nullptr, nullptr, gamma, beta, rows, d, hi, lo, nullptr, s, q, qs, rows_pad);
+    case 1: return launch_mode<MODE, 1>(x, d, dh, dl, nullptr, nullptr, gamma, beta, rows, d, hi, lo, nullptr, s, q, qs, rows_pad);
+    case 2: return launch_mode<MODE, 2>(x, d, dh, dl, nullptr, nullptr, gamma, beta, rows, d, hi, lo, nullptr, s, q, qs, rows_pad);
+    case 3: return launch_mode<MODE, 3>(x, d, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, nullptr, s, q, qs, rows_pad);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 }  // namespace
@@ -157,26 +187,33 @@ hipError_t launch_layernorm(const float* x, int64_t ldx, const float* gamma, con
                             int32_t d, bf16_t* out_hi, bf16_t* out_lo, float* out_f32, hipStream_t s) {
   if (rows <= 0 || d <= 0 || d % 64 != 0) return hipErrorInvalidValue;
   float* xm = const_cast<float*>(x);  // not written without ADD
-  if (out_f32 != nullptr) return launch_mode<2, false>(xm, ldx, nullptr, nullptr, gamma, beta, rows, d, nullptr, nullptr, out_f32, s);
-  if (out_lo != nullptr) return launch_mode<1, false>(xm, ldx, nullptr, nullptr, gamma, beta, rows, d, out_hi, out_lo, nullptr, s);
-  return launch_mode<0, false>(xm, ldx, nullptr, nullptr, gamma, beta, rows, d, out_hi, nullptr, nullptr, s);
+  if (out_f32 != nullptr) return launch_mode<2, 0>(xm, ldx, nullptr, nullptr, nullptr, nullptr, gamma, beta, rows, d, nullptr, nullptr, out_f32, s);
+  if (out_lo != nullptr) return launch_mode<1, 0>(xm, ldx, nullptr, nullptr, nullptr, nullptr, gamma, beta, rows, d, out_hi, out_lo, nullptr, s);
+  return launch_mode<0, 0>(xm, ldx, nullptr, nullptr, nullptr, nullptr, gamma, beta, rows, d, out_hi, nullptr, nullptr, s);
 }
 
 hipError_t launch_add_layernorm(float* x, const bf16_t* delta_hi, const bf16_t* delta_lo, const float* gamma,
                                 const float* beta, int64_t rows, int32_t d, bf16_t* out_hi, bf16_t* out_lo,
                                 hipStream_t s) {
-  if (rows <= 0 || d <= 0 || d % 64 != 0 || delta_hi == nullptr) return hipErrorInvalidValue;
-  if (out_lo != nullptr) return launch_mode<1, true>(x, d, delta_hi, delta_lo, gamma, beta, rows, d, out_hi, out_lo, nullptr, s);
-  return launch_mode<0, true>(x, d, delta_hi, delta_lo, gamma, beta, rows, d, out_hi, nullptr, nullptr, s);
+  return launch_add_layernorm_ex(1, x, delta_hi, delta_lo, nullptr, nullptr, gamma, beta, rows, d, out_hi, out_lo, s);
+}
+
+// add: 1 = x += d1 (written back); 2 = normalise x + d1 without writing x back; 3 = x += d1 + d2 (written back)
+hipError_t launch_add_layernorm_ex(int add, float* x, const bf16_t* d1_hi, const bf16_t* d1_lo, const bf16_t* d2_hi,
+                                   const bf16_t* d2_lo, const float* gamma, const float* beta, int64_t rows, int32_t d,
+                                   bf16_t* out_hi, bf16_t* out_lo, hipStream_t s) {
+  if (rows <= 0 || d <= 0 || d % 64 != 0 || add < 1 || add > 3 || d1_hi == nullptr || (add == 3 && d2_hi == nullptr)) return hipErrorInvalidValue;
+  if (out_lo != nullptr) return launch_add_mode<1>(add, x, d1_hi, d1_lo, d2_hi, d2_lo, gamma, beta, rows, d, out_hi, out_lo, s);
+  return launch_add_mode<0>(add, x, d1_hi, nullptr, d2_hi, nullptr, gamma, beta, rows, d, out_hi, nullptr, s);
 }
 
 // MXFP8 output (the A operand of the fp8 path's QKV / c_fc GEMMs): out_q [rows, d] e4m3, out_sc [d/64][rows_pad][2].
-// delta_hi == nullptr: plain LayerNorm; else x += delta first (written back), as launch_add_layernorm.
-hipError_t launch_layernorm_mx8(float* x, const bf16_t* delta_hi, const float* gamma, const float* beta, int64_t rows, int32_t d,
-                                uint8_t* out_q, uint8_t* out_sc, int64_t rows_pad, hipStream_t s) {
+// add: 0 = plain LayerNorm; 1, 2, 3 as launch_add_layernorm_ex.
+hipError_t launch_layernorm_mx8(int add, float* x, const bf16_t* d1_hi, const bf16_t* d2_hi, const float* gamma, const float* beta,
+                                int64_t rows, int32_t d, uint8_t* out_q, uint8_t* out_sc, int64_t rows_pad, hipStream_t s) {
   if (rows <= 0 || d <= 0 || d % 256 != 0 || d > 1024 || rows_pad < rows || !out_q || !out_sc) return hipErrorInvalidValue;
-  if (delta_hi == nullptr) return launch_mode<3, false>(x, d, nullptr, nullptr, gamma, beta, rows, d, nullptr, nullptr, nullptr, s, out_q, out_sc, rows_pad);
-  return launch_mode<3, true>(x, d, delta_hi, nullptr, gamma, beta, rows, d, nullptr, nullptr, nullptr, s, out_q, out_sc, rows_pad);
+  if ((add >= 1 && d1_hi == nullptr) || (add == 3 && d2_hi == nullptr)) return hipErrorInvalidValue;
+  return launch_add_mode<3>(add, x, d1_hi, nullptr, d2_hi, nullptr, gamma, beta, rows, d, nullptr, nullptr, s, out_q, out_sc, rows_pad);
 }
 
 }  // namespace tapclip

@@ -105,7 +105,8 @@ struct Workspace {
   bf16_t *qkv_hi = nullptr, *qkv_lo = nullptr;
   bf16_t *ao_hi = nullptr, *ao_lo = nullptr;
   bf16_t *h_hi = nullptr, *h_lo = nullptr;
-  bf16_t *d_hi = nullptr, *d_lo = nullptr;  // pending residual branch (out_proj / c_proj output)
+  bf16_t *d_hi = nullptr, *d_lo = nullptr;  // pending residual branch (c_proj output; out_proj's in the backward's recompute)
+  bf16_t *a_hi = nullptr, *a_lo = nullptr;  // forward: out_proj's branch (folded into x by the NEXT block's LN1, with d)
   float* probs = nullptr;
   // fp8 precision: MXFP8 activations live in the front of the bf16 buffers they replace (e4m3 [M, K] then the
   // scales [K/64][m_pad][2]: 1.03 bytes per element against 2)
@@ -136,8 +137,10 @@ Workspace carve(const tapclip_tower* t, int64_t n_seq, int tokens, void* base) {
   w.ao_hi = static_cast<bf16_t*>(take(M * D * 2));
   w.h_hi = static_cast<bf16_t*>(take(hid_elems * 2));
   w.d_hi = static_cast<bf16_t*>(take(M * D * 2));
+  w.a_hi = static_cast<bf16_t*>(take(M * D * 2));
   if (t->split) {
     w.d_lo = static_cast<bf16_t*>(take(M * D * 2));
+    w.a_lo = static_cast<bf16_t*>(take(M * D * 2));
     w.xn_lo = static_cast<bf16_t*>(take(M * D * 2));
     w.qkv_lo = static_cast<bf16_t*>(take(M * 3 * D * 2));
     w.ao_lo = static_cast<bf16_t*>(take(M * D * 2));
@@ -288,7 +291,8 @@ int run_blocks_fp8(tapclip_tower* t, float* x, int64_t n_seq, int tokens, const 
     const LayerW& L = t->layers[li];
     {
       ProfScope ps(t, 1, s);
-      HIP_TRY(launch_layernorm_mx8(x, li == 0 ? nullptr : w.d_hi, L.ln1_g, L.ln1_b, M, D, w.xn_q, w.xn_s, w.m_pad, s));
+      // block l > 0: x still lacks BOTH branches of block l - 1 (its LN2 did not write x back)
+      HIP_TRY(launch_layernorm_mx8(li == 0 ? 0 : 3, x, w.a_hi, w.d_hi, L.ln1_g, L.ln1_b, M, D, w.xn_q, w.xn_s, w.m_pad, s));
     }
     if ((rc = gemm_mx8(t, 2, EPI_BIAS_BF16, w.xn_q, w.xn_s, w.m_pad, L.qqkv, L.bqkv, M, 3 * D, D, w.qkv_hi, nullptr, nullptr, s))) return rc;
     {
@@ -301,10 +305,11 @@ int run_blocks_fp8(tapclip_tower* t, float* x, int64_t n_seq, int tokens, const 
       ProfScope ps(t, 3, s);
       HIP_TRY(launch_attention(a, false, s));
     }
-    if ((rc = gemm_mx8(t, 4, EPI_BIAS_BF16, w.ao_q, w.ao_s, w.m_pad, L.qo, L.bo, M, D, D, w.d_hi, nullptr, nullptr, s))) return rc;
+    if ((rc = gemm_mx8(t, 4, EPI_BIAS_BF16, w.ao_q, w.ao_s, w.m_pad, L.qo, L.bo, M, D, D, w.a_hi, nullptr, nullptr, s))) return rc;
     {
       ProfScope ps(t, 1, s);
-      HIP_TRY(launch_layernorm_mx8(x, w.d_hi, L.ln2_g, L.ln2_b, M, D, w.xn_q, w.xn_s, w.m_pad, s));
+      // the last block folds out_proj's branch into x here, so that only c_proj's is pending on return
+      HIP_TRY(launch_layernorm_mx8(li == t->cfg.layers - 1 ? 1 : 2, x, w.a_hi, nullptr, L.ln2_g, L.ln2_b, M, D, w.xn_q, w.xn_s, w.m_pad, s));
     }
     if ((rc = gemm_mx8(t, 5, EPI_BIAS_GELU_MX8, w.xn_q, w.xn_s, w.m_pad, L.qfc, L.bfc, M, F, D, nullptr, w.h_q, w.h_s, s))) return rc;
     if ((rc = gemm_mx8(t, 6, EPI_BIAS_BF16, w.h_q, w.h_s, w.m_pad, L.qpr, L.bpr, M, D, F, w.d_hi, nullptr, nullptr, s))) return rc;
@@ -325,8 +330,9 @@ int run_blocks(tapclip_tower* t, float* x, int64_t n_seq, int tokens, int causal
     const bool last = li == t->cfg.layers - 1;
     {
       ProfScope ps(t, 1, s);
+      // block l > 0: x still lacks BOTH branches of block l - 1 (its LN2 did not write x back)
       if (li == 0) HIP_TRY(launch_layernorm(x, D, L.ln1_g, L.ln1_b, M, D, w.xn_hi, w.xn_lo, nullptr, s));
-      else HIP_TRY(launch_add_layernorm(x, w.d_hi, w.d_lo, L.ln1_g, L.ln1_b, M, D, w.xn_hi, w.xn_lo, s));
+      else HIP_TRY(launch_add_layernorm_ex(3, x, w.a_hi, w.a_lo, w.d_hi, w.d_lo, L.ln1_g, L.ln1_b, M, D, w.xn_hi, w.xn_lo, s));
     }
     int rc = gemm(t, 2, EPI_BIAS_BF16, w.xn_hi, w.xn_lo, D, L.wqkv, L.bqkv, M, 3 * D, D, w.qkv_hi, w.qkv_lo, nullptr,
                   3 * D, s);
@@ -345,11 +351,13 @@ int run_blocks(tapclip_tower* t, float* x, int64_t n_seq, int tokens, int causal
       rc = gemm(t, 4, EPI_BIAS_F32, w.ao_hi, w.ao_lo, D, L.wo, L.bo, M, D, D, nullptr, nullptr, attn_out_last, D, s);
       if (rc) return rc;
     }
-    rc = gemm(t, 4, EPI_BIAS_BF16, w.ao_hi, w.ao_lo, D, L.wo, L.bo, M, D, D, w.d_hi, w.d_lo, nullptr, D, s);
+    rc = gemm(t, 4, EPI_BIAS_BF16, w.ao_hi, w.ao_lo, D, L.wo, L.bo, M, D, D, w.a_hi, w.a_lo, nullptr, D, s);
     if (rc) return rc;
     {
       ProfScope ps(t, 1, s);
-      HIP_TRY(launch_add_layernorm(x, w.d_hi, w.d_lo, L.ln2_g, L.ln2_b, M, D, w.xn_hi, w.xn_lo, s));
+      // LN2 normalises x + branch without writing x back (8 instead of 12 B/element); the last block does write,
+      // so that only c_proj's branch is pending on return
+      HIP_TRY(launch_add_layernorm_ex(last ? 1 : 2, x, w.a_hi, w.a_lo, nullptr, nullptr, L.ln2_g, L.ln2_b, M, D, w.xn_hi, w.xn_lo, s));
     }
     rc = gemm(t, 5, EPI_BIAS_GELU_BF16, w.xn_hi, w.xn_lo, D, L.wfc, L.bfc, M, F, D, w.h_hi, w.h_lo, nullptr, F, s);
     if (rc) return rc;
