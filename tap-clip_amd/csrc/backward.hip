@@ -46,10 +46,12 @@ __device__ __forceinline__ f32x4_t mfma4(float a, float b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
+template <int NT>  // NT = Tp / 16 key / query tiles: compile-time trip counts, so the LDS reads of a product pipeline
+__global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs a) {
   extern __shared__ float sh[];
   const int T = a.T, D = a.D;
-  const int Tp = (T + 15) & ~15, nt = Tp >> 4, LP = Tp + 1;
+  constexpr int Tp = NT * 16, nt = NT, LP = Tp + 1;
+  constexpr int NW = 8;  // waves
   float* q = sh;
   float* k = q + Tp * BWD_LD;
   float* v = k + Tp * BWD_LD;
@@ -64,23 +66,47 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
   const int64_t ld = 3 * (int64_t)D;
   const int qcol = head * 64, kcol = D + head * 64, vcol = 2 * D + head * 64;
 
-  for (int e = tid; e < Tp * 64; e += 256) {
-    const int i = e >> 6, d = e & 63;
-    float fq = 0.f, fk = 0.f, fv = 0.f, fo = 0.f;
+  // stage q, k, v, dO as fp32: 8 bf16 (16 B) per thread and array, hi (+ lo) planes
+  for (int e = tid; e < Tp * 8; e += 512) {
+    const int i = e >> 3, d0 = (e & 7) * 8;
+    float fq[8], fk[8], fv[8], fo[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) fq[u] = fk[u] = fv[u] = fo[u] = 0.f;
     if (i < T) {
-      const int64_t g = (row0 + i) * ld + d;
-      fq = ld_bf(a.qkv_hi, a.qkv_lo, g + qcol);
-      fk = ld_bf(a.qkv_hi, a.qkv_lo, g + kcol);
-      fv = ld_bf(a.qkv_hi, a.qkv_lo, g + vcol);
-      fo = ld_bf(a.dout_hi, a.dout_lo, (row0 + i) * D + head * 64 + d);
+      auto ld8 = [&](const bf16_t* hi, const bf16_t* lo, int64_t g, float (&f)[8]) {
+        const uint4 h = *reinterpret_cast<const uint4*>(hi + g);
+        const uint32_t hw[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          f[2 * u] = bf2f((bf16_t)(hw[u] & 0xFFFF));
+          f[2 * u + 1] = bf2f((bf16_t)(hw[u] >> 16));
+        }
+        if (lo != nullptr) {
+          const uint4 l = *reinterpret_cast<const uint4*>(lo + g);
+          const uint32_t lw[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            f[2 * u] += bf2f((bf16_t)(lw[u] & 0xFFFF));
+            f[2 * u + 1] += bf2f((bf16_t)(lw[u] >> 16));
+          }
+        }
+      };
+      const int64_t g = (row0 + i) * ld + d0;
+      ld8(a.qkv_hi, a.qkv_lo, g + qcol, fq);
+      ld8(a.qkv_hi, a.qkv_lo, g + kcol, fk);
+      ld8(a.qkv_hi, a.qkv_lo, g + vcol, fv);
+      ld8(a.dout_hi, a.dout_lo, (row0 + i) * D + head * 64 + d0, fo);
     }
-    q[i * BWD_LD + d] = fq;
-    k[i * BWD_LD + d] = fk;
-    v[i * BWD_LD + d] = fv;
-    dO[i * BWD_LD + d] = fo;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      q[i * BWD_LD + d0 + u] = fq[u];
+      k[i * BWD_LD + d0 + u] = fk[u];
+      v[i * BWD_LD + d0 + u] = fv[u];
+      dO[i * BWD_LD + d0 + u] = fo[u];
+    }
   }
   // delta_i = <dO_i, O_i>: one wave per row, O read straight from global
-  for (int i = wave; i < Tp; i += 4) {
+  for (int i = wave; i < Tp; i += NW) {
     float s = 0.f;
     if (i < T) {
       const int64_t g = (row0 + i) * D + head * 64 + lane;
@@ -92,7 +118,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
   __syncthreads();
 
   // S[i][j] = q_i . k_j   (tile (ti, tj): A = q rows, B = k rows, K = 64)
-  for (int tile = wave; tile < nt * nt; tile += 4) {
+  for (int tile = wave; tile < nt * nt; tile += NW) {
     const int ti = tile / nt, tj = tile - ti * nt;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     const float* qa = q + (ti * 16 + lr) * BWD_LD + lq;
@@ -109,7 +135,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
   }
   __syncthreads();
   // row softmax (pad query rows see all-finite scores of zero vectors; their dO is zero, so they never count)
-  for (int i = wave; i < Tp; i += 4) {
+  for (int i = wave; i < Tp; i += NW) {
     float mx = -INFINITY;
     for (int j = lane; j < Tp; j += 64) mx = fmaxf(mx, P[i * LP + j]);
     mx = wave_max(mx);
@@ -125,9 +151,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
   }
   __syncthreads();
   // dV[j][d] = sum_i P[i][j] dO[i][d]   (tile (tj, td): A[row j][k i] = P[i][j], B[k i][col d] = dO[i][d], K = Tp)
-  for (int tile = wave; tile < nt * 4; tile += 4) {
+  for (int tile = wave; tile < nt * 4; tile += NW) {
     const int tj = tile >> 2, td = tile & 3;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
     for (int i0 = 0; i0 < Tp; i0 += 4)
       acc = mfma4(P[(i0 + lq) * LP + tj * 16 + lr], dO[(i0 + lq) * BWD_LD + td * 16 + lr], acc);
 #pragma unroll
@@ -138,7 +165,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
   }
   __syncthreads();
   // dS[i][j] = P[i][j] (dO_i . v_j - delta_i), in place
-  for (int tile = wave; tile < nt * nt; tile += 4) {
+  for (int tile = wave; tile < nt * nt; tile += NW) {
     const int ti = tile / nt, tj = tile - ti * nt;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     const float* oa = dO + (ti * 16 + lr) * BWD_LD + lq;
@@ -153,15 +180,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
   }
   __syncthreads();
   // dq[i][d] = sum_j dS[i][j] k[j][d];   dk[j][d] = sum_i dS[i][j] q[i][d]
-  for (int tile = wave; tile < nt * 4 * 2; tile += 4) {
+  for (int tile = wave; tile < nt * 4 * 2; tile += NW) {
     const bool is_dk = tile >= nt * 4;
     const int tl = is_dk ? tile - nt * 4 : tile;
     const int tr = tl >> 2, td = tl & 3;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     if (!is_dk) {
+#pragma unroll
       for (int j0 = 0; j0 < Tp; j0 += 4)
         acc = mfma4(P[(tr * 16 + lr) * LP + j0 + lq], k[(j0 + lq) * BWD_LD + td * 16 + lr], acc);
     } else {
+#pragma unroll
       for (int i0 = 0; i0 < Tp; i0 += 4)
         acc = mfma4(P[(i0 + lq) * LP + tr * 16 + lr], q[(i0 + lq) * BWD_LD + td * 16 + lr], acc);
     }
@@ -312,19 +341,31 @@ size_t attn_bwd_lds_bytes(int T) {
   return (size_t)(4 * Tp * BWD_LD + Tp * (Tp + 1) + Tp) * sizeof(float);
 }
 
+template <int NT>
+hipError_t launch_attn_bwd_t(const AttnBwdArgs& a, size_t lds, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)attn_bwd_lds_bytes(NT * 16));
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(attn_bwd_kernel<NT>, dim3((unsigned)(a.n_seq * a.H)), dim3(512), lds, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s) {
-  if (a.T <= 0 || a.T > 96 || a.D != a.H * 64 || a.n_seq <= 0) return hipErrorInvalidValue;
+  if (a.T <= 0 || a.T > 96 || a.D != a.H * 64 || a.n_seq <= 0 || a.D % 8 != 0) return hipErrorInvalidValue;
   const size_t lds = attn_bwd_lds_bytes(a.T);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  static size_t attr = 0;
-  if (lds > attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr = lds;
+  switch ((a.T + 15) / 16) {
+    case 1: return launch_attn_bwd_t<1>(a, lds, s);
+    case 2: return launch_attn_bwd_t<2>(a, lds, s);
+    case 3: return launch_attn_bwd_t<3>(a, lds, s);
+    case 4: return launch_attn_bwd_t<4>(a, lds, s);
+    case 5: return launch_attn_bwd_t<5>(a, lds, s);
+    default: return launch_attn_bwd_t<6>(a, lds, s);
   }
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(a.n_seq * a.H)), dim3(256), lds, s, a);
-  return hipGetLastError();
 }
 
 hipError_t launch_ln_bwd(const float* x, const float* gamma, const float* dy, int64_t rows, int32_t d, float* dres,
