@@ -125,6 +125,20 @@ int tapclip_text_pool_project(tapclip_tower_t* text, const float* hidden, int32_
                               int32_t tokens, const int64_t* index, int32_t apply_ln_final,
                               int32_t normalize, float* out, tapclip_stream_t stream);
 
+/* The same backward without the recomputation: tapclip_text_forward_saved runs the blocks (no attention
+ * write-back) and keeps, in caller memory of tapclip_text_saved_bytes(), the residual stream before each
+ * LayerNorm, q|k|v and the attention output of every block; tapclip_text_backward_saved consumes them.
+ * grad_x may alias grad_hidden.  The pair replaces tapclip_text_forward + tapclip_text_backward inside a
+ * training step (reference train.py:99-105), where the forward is otherwise run twice. */
+size_t tapclip_text_saved_bytes(const tapclip_tower_t* tower, int64_t n_seq, int32_t tokens);
+int tapclip_text_forward_saved(tapclip_tower_t* tower, const float* x_in, int32_t n_seq, int32_t tokens,
+                               int32_t causal, float* out_hidden, void* saved, size_t saved_bytes,
+                               void* workspace, size_t workspace_bytes, tapclip_stream_t stream);
+int tapclip_text_backward_saved(tapclip_tower_t* tower, const void* saved, size_t saved_bytes,
+                                const float* grad_hidden, int32_t n_seq, int32_t tokens, int32_t causal,
+                                float* grad_x, void* workspace, size_t workspace_bytes,
+                                tapclip_stream_t stream);
+
 /* ---- prompt-tuning backward (reference train.py:99-105: `loss.backward()`; only
  * `prompt_learner.context_bank.*` and `logit_scale` receive gradients, every CLIP weight is frozen,
  * clip_wrapper.py:19-20, so these are dX-only).  Stateless: tapclip_text_backward recomputes the forward

@@ -32,6 +32,9 @@ SYMBOLS = [
     ("tapclip_text_pool_project", _i32, [_p, _p, _i32, _i32, _p, _i32, _i32, _p, _p]),
     ("tapclip_text_backward_workspace_bytes", _sz, [_p, _i64, _i32]),
     ("tapclip_text_backward", _i32, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _sz, _p]),
+    ("tapclip_text_saved_bytes", _sz, [_p, _i64, _i32]),
+    ("tapclip_text_forward_saved", _i32, [_p, _p, _i32, _i32, _i32, _p, _p, _sz, _p, _sz, _p]),
+    ("tapclip_text_backward_saved", _i32, [_p, _p, _sz, _p, _i32, _i32, _i32, _p, _p, _sz, _p]),
     ("tapclip_text_pool_project_backward", _i32, [_p, _p, _i32, _i32, _i32, _p, _p, _p]),
     ("tapclip_logits_backward", _i32, [_p, _p, _p, _f32, _i32, _i32, _i32, _p, _p, _p]),
     ("tapclip_embed_tokens", _i32, [_p, _p, _i32, _i32, _i32, _p, _p]),

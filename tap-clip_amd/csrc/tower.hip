@@ -399,8 +399,10 @@ Saved carve_saved(const tapclip_tower* t, int64_t M, void* base) {
 // Forward of the text tower again, keeping what the backward needs (activation recomputation keeps the C ABI
 // stateless: nothing is remembered between tapclip_text_forward and tapclip_text_backward), then the
 // backward sweep.  dx (fp32 [M, D]) enters holding dL/d(hidden) and leaves holding dL/d(x_in).
-int run_backward(tapclip_tower* t, const float* x_in, float* dx, int64_t n_seq, int tokens, int causal,
-                 const Workspace& w, const Saved& sv, hipStream_t s) {
+// Forward of the blocks that keeps what the backward needs (sv): the residual stream before each LayerNorm, q|k|v and
+// the attention output of every block.  On return w.x holds x without the last c_proj branch, which is pending in w.d.
+int run_forward_saving(tapclip_tower* t, const float* x_in, int64_t n_seq, int tokens, int causal, const Workspace& w,
+                       const Saved& sv, hipStream_t s) {
   const int64_t M = n_seq * tokens;
   const int D = t->cfg.width, F = t->cfg.mlp_dim, H = t->cfg.heads, L = t->cfg.layers;
   float* x = w.x;
@@ -425,8 +427,17 @@ int run_backward(tapclip_tower* t, const float* x_in, float* dx, int64_t n_seq, 
     if ((rc = gemm(t, 5, EPI_BIAS_GELU_BF16, w.xn_hi, w.xn_lo, D, Lw.wfc, Lw.bfc, M, F, D, w.h_hi, w.h_lo, nullptr, F, s))) return rc;
     if ((rc = gemm(t, 6, EPI_BIAS_BF16, w.h_hi, w.h_lo, F, Lw.wpr, Lw.bpr, M, D, F, w.d_hi, w.d_lo, nullptr, D, s))) return rc;
   }
-  // ---- backward sweep.  Scratch re-uses the forward workspace: g = w.d (branch gradient as a GEMM operand),
-  // w.h = dL/dh then dL/dz, w.ao = dL/d(attention out), w.qkv = dL/d(qkv), w.x = fp32 dL/d(LN output)
+  return TAPCLIP_OK;
+}
+
+// Backward sweep over the saved activations.  dx (fp32 [M, D]) enters holding dL/d(hidden) and leaves holding
+// dL/d(x_in).  Scratch re-uses the forward workspace: g = w.d (branch gradient as a GEMM operand),
+// w.h = dL/dh then dL/dz, w.ao = dL/d(attention out), w.qkv = dL/d(qkv), w.x = fp32 dL/d(LN output)
+int run_backward_sweep(tapclip_tower* t, float* dx, int64_t n_seq, int tokens, int causal, const Workspace& w,
+                       const Saved& sv, hipStream_t s) {
+  const int64_t M = n_seq * tokens;
+  const int D = t->cfg.width, F = t->cfg.mlp_dim, H = t->cfg.heads, L = t->cfg.layers;
+  int rc;
   float* dn = w.x;
   for (int li = L - 1; li >= 0; --li) {
     const LayerW& Lw = t->layers[li];
@@ -451,6 +462,14 @@ int run_backward(tapclip_tower* t, const float* x_in, float* dx, int64_t n_seq, 
     HIP_TRY(launch_ln_bwd(sv.x0[li], Lw.ln1_g, dn, M, D, dx, s));
   }
   return TAPCLIP_OK;
+}
+
+// Forward again (activation recomputation keeps tapclip_text_backward stateless), then the sweep.
+int run_backward(tapclip_tower* t, const float* x_in, float* dx, int64_t n_seq, int tokens, int causal,
+                 const Workspace& w, const Saved& sv, hipStream_t s) {
+  int rc = run_forward_saving(t, x_in, n_seq, tokens, causal, w, sv, s);
+  if (rc) return rc;
+  return run_backward_sweep(t, dx, n_seq, tokens, causal, w, sv, s);
 }
 
 int check_ready(const tapclip_tower* t) {
@@ -716,6 +735,50 @@ int tapclip_text_backward(tapclip_tower_t* t, const float* x_in, const float* gr
   if (grad_x != grad_hidden)
     HIP_TRY(hipMemcpyAsync(grad_x, grad_hidden, (size_t)n_seq * tokens * t->cfg.width * 4, hipMemcpyDeviceToDevice, s));
   return run_backward(t, x_in, grad_x, n_seq, tokens, causal, w, sv, s);
+}
+
+size_t tapclip_text_saved_bytes(const tapclip_tower_t* t, int64_t n_seq, int32_t tokens) {
+  if (!t || n_seq <= 0 || tokens <= 0 || t->cfg.kind != TAPCLIP_TOWER_TEXT) return 0;
+  return carve_saved(t, n_seq * tokens, nullptr).bytes;
+}
+
+int tapclip_text_forward_saved(tapclip_tower_t* t, const float* x_in, int32_t n_seq, int32_t tokens, int32_t causal,
+                               float* out_hidden, void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes,
+                               tapclip_stream_t stream) {
+  if (!t || !x_in || !out_hidden || !saved || !workspace) return fail(TAPCLIP_EINVAL, "null argument");
+  if (t->cfg.kind != TAPCLIP_TOWER_TEXT) return fail(TAPCLIP_EINVAL, "text_forward_saved needs a text tower");
+  if (n_seq <= 0 || tokens <= 0) return fail(TAPCLIP_EINVAL, "bad n_seq/tokens");
+  int rc = check_ready(t);
+  if (rc) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t M = (int64_t)n_seq * tokens;
+  const Workspace w = carve(t, n_seq, tokens, workspace);
+  if (w.bytes > workspace_bytes) return fail(TAPCLIP_EWORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, w.bytes);
+  const Saved sv = carve_saved(t, M, saved);
+  if (sv.bytes > saved_bytes) return fail(TAPCLIP_EWORKSPACE, "saved buffer %zu B < required %zu B", saved_bytes, sv.bytes);
+  if ((rc = run_forward_saving(t, x_in, n_seq, tokens, causal, w, sv, s))) return rc;
+  HIP_TRY(hipMemcpyAsync(out_hidden, w.x, (size_t)M * t->cfg.width * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(launch_add_delta(out_hidden, w.d_hi, w.d_lo, M * t->cfg.width, s));  // last pending branch
+  return TAPCLIP_OK;
+}
+
+int tapclip_text_backward_saved(tapclip_tower_t* t, const void* saved, size_t saved_bytes, const float* grad_hidden, int32_t n_seq,
+                                int32_t tokens, int32_t causal, float* grad_x, void* workspace, size_t workspace_bytes,
+                                tapclip_stream_t stream) {
+  if (!t || !saved || !grad_hidden || !grad_x || !workspace) return fail(TAPCLIP_EINVAL, "null argument");
+  if (t->cfg.kind != TAPCLIP_TOWER_TEXT) return fail(TAPCLIP_EINVAL, "text_backward_saved needs a text tower");
+  if (n_seq <= 0 || tokens <= 0) return fail(TAPCLIP_EINVAL, "bad n_seq/tokens");
+  if (attn_bwd_lds_bytes(tokens) > 160 * 1024) return fail(TAPCLIP_EINVAL, "text_backward supports at most 96 tokens per sequence (got %d)", tokens);
+  int rc = check_ready(t);
+  if (rc) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t M = (int64_t)n_seq * tokens;
+  const Workspace w = carve(t, n_seq, tokens, workspace);
+  if (w.bytes > workspace_bytes) return fail(TAPCLIP_EWORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, w.bytes);
+  const Saved sv = carve_saved(t, M, const_cast<void*>(saved));
+  if (sv.bytes > saved_bytes) return fail(TAPCLIP_EWORKSPACE, "saved buffer %zu B < required %zu B", saved_bytes, sv.bytes);
+  if (grad_x != grad_hidden) HIP_TRY(hipMemcpyAsync(grad_x, grad_hidden, (size_t)M * t->cfg.width * 4, hipMemcpyDeviceToDevice, s));
+  return run_backward_sweep(t, grad_x, n_seq, tokens, causal, w, sv, s);
 }
 
 int tapclip_text_pool_project_backward(tapclip_tower_t* t, const float* hidden, int32_t n_seq, int32_t tokens, int32_t normalize,

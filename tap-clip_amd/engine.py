@@ -185,6 +185,30 @@ class TextTower(_Tower):
                                                       _ptr(self._ws), self._ws.numel(), _stream_ptr(self.device)))
         return out
 
+    def forward_saved(self, x: torch.Tensor, causal: bool = False):
+        """Training forward: hidden [n,T,D] plus an opaque buffer of saved activations for `backward_saved`
+        (no attention write-back; `tapclip_text_forward_saved`)."""
+        xin = _dev_f32(x, self.device)
+        n, T, D = xin.shape
+        hidden = torch.empty_like(xin)
+        with torch.cuda.device(self.device):
+            saved = torch.empty(int(self.lib.tapclip_text_saved_bytes(self.handle, n, T)), dtype=torch.uint8, device=self.device)
+            ws, nbytes = self.workspace(n, T)
+            _lib.check(self.lib.tapclip_text_forward_saved(self.handle, _ptr(xin), n, T, int(causal), _ptr(hidden), _ptr(saved),
+                                                           saved.numel(), _ptr(ws), nbytes, _stream_ptr(self.device)))
+        return hidden, saved
+
+    def backward_saved(self, saved: torch.Tensor, grad_hidden: torch.Tensor, causal: bool = False) -> torch.Tensor:
+        """dL/dx from the activations kept by `forward_saved` (no recomputation; `tapclip_text_backward_saved`)."""
+        g = _dev_f32(grad_hidden, self.device)
+        n, T, D = g.shape
+        out = torch.empty_like(g)
+        with torch.cuda.device(self.device):
+            ws, nbytes = self.workspace(n, T)
+            _lib.check(self.lib.tapclip_text_backward_saved(self.handle, _ptr(saved), saved.numel(), _ptr(g), n, T, int(causal),
+                                                            _ptr(out), _ptr(ws), nbytes, _stream_ptr(self.device)))
+        return out
+
     def pool_project_backward(self, hidden: torch.Tensor, grad_out: torch.Tensor, normalize: bool = True) -> torch.Tensor:
         """backward of `pool_project(hidden, index=None, ln_final=False, normalize)`: [n,E] -> [n,T,D]."""
         h = _dev_f32(hidden, self.device)

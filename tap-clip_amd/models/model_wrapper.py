@@ -37,16 +37,19 @@ class _TextTowerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, prompts, clip):
         tower = clip._text
-        hidden = clip.model.transformer(prompts.detach())
+        # the blocks keep their activations for the backward (no recomputation); like the reference's second
+        # pass (model_wrapper.py:72) this call also leaves a capture in clip.attention_maps -- not needed here,
+        # so the hook list is left as pass 1 filled it
+        hidden, saved = tower.forward_saved(prompts.detach())
         ctx.tower = tower
-        ctx.save_for_backward(prompts.detach(), hidden)
+        ctx.save_for_backward(hidden, saved)
         return tower.pool_project(hidden, index=None, ln_final=False, normalize=True)
 
     @staticmethod
     def backward(ctx, grad_feat):
-        prompts, hidden = ctx.saved_tensors
+        hidden, saved = ctx.saved_tensors
         g_hidden = ctx.tower.pool_project_backward(hidden, grad_feat.contiguous(), normalize=True)
-        return ctx.tower.backward(prompts, g_hidden), None
+        return ctx.tower.backward_saved(saved, g_hidden), None
 
 
 class _LogitsFn(torch.autograd.Function):

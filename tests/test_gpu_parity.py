@@ -407,6 +407,18 @@ def test_text_backward_real_dims_vs_oracle_autograd(eng, precision):
     assert rel_max(gx[:, :16], xr.grad[:, :16]) < tol  # the context-token rows FullModel uses
 
 
+def test_text_backward_saved_equals_recompute(eng):
+    """`forward_saved` + `backward_saved` (what a training step uses) against `forward` + the recomputing `backward`."""
+    cfg = configs.get_config("tiny")
+    sd = synth.make_state_dict(cfg, seed=2)
+    tower = eng.TextTower(cfg, sd, DEV, "bf16")
+    x = synth.normal([7, 21, cfg.text.width], 31, "saved.x").to(DEV)
+    g = synth.normal([7, 21, cfg.text.width], 32, "saved.g").to(DEV)
+    hidden, saved = tower.forward_saved(x)
+    assert rel_max(hidden.cpu(), tower.forward(x)["hidden"].cpu()) < 1e-6
+    assert torch.equal(tower.backward_saved(saved, g), tower.backward(x, g))
+
+
 def test_train_step_reduces_loss():
     """A few AdamW steps on context_bank only (reference train.py:65-67,99-105) lower the loss."""
     g = golden("fullmodel_intended_tiny")
