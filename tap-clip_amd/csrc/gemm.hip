@@ -173,12 +173,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
       }
       if (EPI == EPI_GELU_BWD_BF16) {
         const int64_t o = orow * g.ldo + n;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float up = bf2f(g.aux_hi[o + e]);
-          if (SPLIT) up += bf2f(g.aux_lo[o + e]);
-          v[e] = (g.act == 0 ? gelu_erf_grad(v[e]) : gelu_quick_grad(v[e])) * up;
+        const uint2 uh = *reinterpret_cast<const uint2*>(g.aux_hi + o);  // the 4 upstream gradients of this lane: one 8-byte load
+        float up[4] = {bf2f((bf16_t)(uh.x & 0xFFFF)), bf2f((bf16_t)(uh.x >> 16)), bf2f((bf16_t)(uh.y & 0xFFFF)), bf2f((bf16_t)(uh.y >> 16))};
+        if (SPLIT) {
+          const uint2 ul = *reinterpret_cast<const uint2*>(g.aux_lo + o);
+          up[0] += bf2f((bf16_t)(ul.x & 0xFFFF)); up[1] += bf2f((bf16_t)(ul.x >> 16));
+          up[2] += bf2f((bf16_t)(ul.y & 0xFFFF)); up[3] += bf2f((bf16_t)(ul.y >> 16));
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (g.act == 0 ? gelu_erf_grad(v[e]) : gelu_quick_grad(v[e])) * up[e];
       }
       if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_GELU_BWD_BF16) {
         bf16_t h[4], l[4];
