@@ -332,40 +332,56 @@ __global__ __launch_bounds__(512) void attn_flash_kernel(AttnArgs a) {
 
   const int n_kb = (T + KEYS - 1) / KEYS;
   const int qq = r >> 2, pp = r & 3;
-  for (int kb = 0; kb < n_kb; ++kb) {
-    const int key_base = kb * KEYS;
-    __syncthreads();  // every wave is done reading the previous block
-    constexpr int N_IT = KEYS * 8 / 512;
+  // K/V rows of a key block: global -> registers -> LDS.  Without the hi/lo split the registers of block kb + 1 are
+  // loaded BEFORE block kb is computed (the workgroup is alone on its CU at this register count, so nothing else
+  // would hide that latency) and written to LDS after it.
+  constexpr int N_IT = KEYS * 8 / 512;
+  constexpr bool PREFETCH = !SPLIT;
+  uint4 kvr[N_IT], vvr[N_IT], kvlr[SPLIT ? N_IT : 1], vvlr[SPLIT ? N_IT : 1];
+  auto fetch_block = [&](int kb) {
 #pragma unroll
     for (int it = 0; it < N_IT; ++it) {
       const int c = tid + 512 * it;
       const int kk = c >> 3, kc = c & 7;
-      const int key = key_base + kk;
-      uint4 kv = make_uint4(0, 0, 0, 0), vv = kv, kvl = kv, vvl = kv;
+      const int key = kb * KEYS + kk;
+      kvr[it] = make_uint4(0, 0, 0, 0);
+      vvr[it] = kvr[it];
+      if (SPLIT) {
+        kvlr[it] = kvr[it];
+        vvlr[it] = kvr[it];
+      }
       if (key < T) {
         const int64_t base = (row0 + key) * ld + kc * 8;
-        kv = *reinterpret_cast<const uint4*>(a.qkv_hi + base + kcol);
-        vv = *reinterpret_cast<const uint4*>(a.qkv_hi + base + vcol);
+        kvr[it] = *reinterpret_cast<const uint4*>(a.qkv_hi + base + kcol);
+        vvr[it] = *reinterpret_cast<const uint4*>(a.qkv_hi + base + vcol);
         if (SPLIT) {
-          kvl = *reinterpret_cast<const uint4*>(a.qkv_lo + base + kcol);
-          vvl = *reinterpret_cast<const uint4*>(a.qkv_lo + base + vcol);
+          kvlr[it] = *reinterpret_cast<const uint4*>(a.qkv_lo + base + kcol);
+          vvlr[it] = *reinterpret_cast<const uint4*>(a.qkv_lo + base + vcol);
         }
       }
+    }
+  };
+  if (PREFETCH) fetch_block(0);
+  for (int kb = 0; kb < n_kb; ++kb) {
+    const int key_base = kb * KEYS;
+    __syncthreads();  // every wave is done reading the previous block
+    if (!PREFETCH) fetch_block(kb);
+#pragma unroll
+    for (int it = 0; it < N_IT; ++it) {
+      const int c = tid + 512 * it;
+      const int kk = c >> 3, kc = c & 7;
       const int ko = kk * 128 + ((kc ^ (kk & 7)) << 4);
       const int vs = (kk >> 1) & 3;  // quad swizzle of the V image, as in attn_kernel
       const int vo = kk * 128 + ((kc >> 1) << 5) + (((kc & 1) ^ (vs >> 1)) << 4);
-      if (vs & 1) {
-        vv = make_uint4(vv.z, vv.w, vv.x, vv.y);
-        vvl = make_uint4(vvl.z, vvl.w, vvl.x, vvl.y);
-      }
-      *reinterpret_cast<uint4*>(Kh + ko) = kv;
-      *reinterpret_cast<uint4*>(Vh + vo) = vv;
+      *reinterpret_cast<uint4*>(Kh + ko) = kvr[it];
+      *reinterpret_cast<uint4*>(Vh + vo) = (vs & 1) ? make_uint4(vvr[it].z, vvr[it].w, vvr[it].x, vvr[it].y) : vvr[it];
       if (SPLIT) {
-        *reinterpret_cast<uint4*>(Kl + ko) = kvl;
-        *reinterpret_cast<uint4*>(Vl + vo) = vvl;
+        *reinterpret_cast<uint4*>(Kl + ko) = kvlr[it];
+        *reinterpret_cast<uint4*>(Vl + vo) = (vs & 1) ? make_uint4(vvlr[it].z, vvlr[it].w, vvlr[it].x, vvlr[it].y) : vvlr[it];
       }
     }
     __syncthreads();
+    if (PREFETCH && kb + 1 < n_kb) fetch_block(kb + 1);  // in flight during the products below
 
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
