@@ -18,6 +18,9 @@ Extra objects on the same line:
                 against the 2.5 PFLOP/s dense bf16 peak (5 PFLOP/s for --precision fp8).
   cpu_baseline  the CPU fp32 oracle (oracle/clip_ref.py, a port: open_clip is absent) on a bounded
                 sample of the same workload, rank 0, N = 1 only.
+  precisions    the same step in the image tower's other 16-/8-bit precisions (bf16, fp16 = the IEEE-half build of
+                the same kernels, fp8 = MXFP8 block GEMMs), each with its embedding error measured live against
+                the split-bf16 parity mode.
   full_forward  FullModel.forward at configs[2] (image + text towers, 65 classes, 16 context tokens,
                 attention-map write-back on): logits/s, measured after the timed region.
 """
@@ -64,10 +67,11 @@ def main():
     ap.add_argument("--model", default="ViT-B-16")
     ap.add_argument("--classes", type=int, default=65)
     ap.add_argument("--prompt-len", type=int, default=16)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "fp8"],
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "fp8", "fp16"],
                     help="bf16 = the benchmarked fast path; bf16x3 = the split-bf16 parity mode (3 MFMA products)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-forward", action="store_true")
+    ap.add_argument("--no-precisions", action="store_true", help="skip the bf16 / fp16 / fp8 comparison table")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
 
@@ -267,6 +271,32 @@ def main():
         result["train_step"] = {"workload": "prompt-tuning step: FullModel forward + CE + backward to 65 x [16,512] context tokens + AdamW, "
                                             "batch %d (image tower forward only: frozen)" % args.batch,
                                 "ms_per_step": round(1e3 * dt_t, 3), "images_per_sec": round(args.batch / dt_t, 1)}
+    if rank == 0 and world == 1 and not args.no_precisions:
+        # The other precisions of the image tower on the same step (fewer steps), each with its live embedding error
+        # against the split-bf16 parity mode (itself 4e-6 from the fp32 reference, tests/test_gpu_parity.py).
+        del model
+        with torch.no_grad():
+            ref_emb = engine.VisionTower(cfg, sd, dev, "bf16x3").encode_image(images, normalize=True)
+            table = {}
+            n_it = max(3, min(10, args.steps))
+            for prec in ("bf16", "fp16", "fp8"):
+                if prec == "fp8" and (cfg.vision.width % 256 or cfg.vision.mlp % 256):
+                    continue
+                tw = vision if prec == args.precision else engine.VisionTower(cfg, sd, dev, prec)
+                for _ in range(2):
+                    e = tw.encode_image(images, normalize=True)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(n_it):
+                    e = tw.encode_image(images, normalize=True)
+                    engine.logits(e, text_feat, scale)
+                torch.cuda.synchronize(dev)
+                dt_p = (time.perf_counter() - t1) / n_it
+                table[prec] = {"img_per_s": round(args.batch / dt_p, 1), "ms_per_step": round(1e3 * dt_p, 3),
+                               "embedding_rel_l2_vs_bf16x3": float("%.3e" % float((e - ref_emb).norm() / ref_emb.norm()))}
+                if tw is not vision:
+                    tw.close()
+        result["precisions"] = table
     if world > 1:
         dist.barrier()
 

@@ -10,6 +10,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libtapclip.so")
+# the same sources compiled with IEEE-half operands instead of bf16 (csrc/common.h TAPCLIP_FP16): precision "fp16"
+LIB_PATH_FP16 = os.path.join(_HERE, "csrc", "libtapclip_fp16.so")
 
 # (name, restype, argtypes) -- must list every symbol include/tapclip.h declares
 _i32, _i64, _f32 = C.c_int32, C.c_int64, C.c_float
@@ -55,43 +57,45 @@ SYMBOLS = [
 TOWER_VISION, TOWER_TEXT = 0, 1
 ACT_GELU_ERF, ACT_QUICK_GELU = 0, 1
 PREC_BF16, PREC_BF16X3, PREC_FP8 = 0, 1, 2
-PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp8": PREC_FP8}
+# "fp16" is the bf16 code path of the IEEE-half build of the library
+PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp8": PREC_FP8, "fp16": PREC_BF16}
 PROFILE_SLOTS = ("patch_embed", "layernorm", "gemm_qkv", "attention", "gemm_out_proj", "gemm_fc_gelu",
                  "gemm_proj", "pool_proj")
 
 EINVAL, ENOMEM, EHIP, ESTATE, EWORKSPACE = -1, -2, -3, -4, -5
 
-_lib = None
+_libs = {}
 
 
-def load() -> C.CDLL:
-    """Load libtapclip.so and bind every symbol.  Raises (never falls back) when it is missing."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(variant: str = "bf16") -> C.CDLL:
+    """Load libtapclip.so (variant "bf16") or libtapclip_fp16.so ("fp16") and bind every symbol.  Raises (never
+    falls back) when it is missing."""
+    if variant in _libs:
+        return _libs[variant]
+    path = LIB_PATH_FP16 if variant == "fp16" else LIB_PATH
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} not found: build the HIP extension first "
+            f"{path} not found: build the HIP extension first "
             "(`python -c 'import __graft_entry__ as g; g.build()'` or `make -C tap-clip_amd/csrc`). "
             "There is no CPU fallback."
         )
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
     if lib.tapclip_abi_version() != 1:
         raise ImportError(f"libtapclip ABI version {lib.tapclip_abi_version()} != 1")
-    _lib = lib
+    _libs[variant] = lib
     return lib
 
 
-def check(rc: int) -> None:
+def check(rc: int, lib=None) -> None:
     """0 -> ok; TAPCLIP_EINVAL -> ValueError (the reference raises ValueError on bad shapes/methods,
     reference models/prompt_learner.py:60, models/prompt_adjustor.py:47); others -> RuntimeError."""
     if rc == 0:
         return
-    msg = load().tapclip_last_error().decode(errors="replace")
+    msg = (lib or load()).tapclip_last_error().decode(errors="replace")
     if rc == EINVAL:
         raise ValueError(f"tapclip: {msg}")
     raise RuntimeError(f"tapclip error {rc}: {msg}")

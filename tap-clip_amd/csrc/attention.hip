@@ -185,11 +185,11 @@ __global__ __launch_bounds__(512) void attn_kernel(AttnArgs a) {
       for (int s = 0; s < 2; ++s) {
         const int off = key * 128 + (((4 * s + g) ^ (key & 7)) << 4);
         const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Kh + off);
-        sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qh[t][s], sc[kt], 0, 0, 0);
+        sc[kt] = TAPCLIP_MFMA_16x16x32(kf, qh[t][s], sc[kt]);
         if (SPLIT) {
           const bf16x8_t kfl = *reinterpret_cast<const bf16x8_t*>(Kl + off);
-          sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfl, qh[t][s], sc[kt], 0, 0, 0);
-          sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, ql[t][s], sc[kt], 0, 0, 0);
+          sc[kt] = TAPCLIP_MFMA_16x16x32(kfl, qh[t][s], sc[kt]);
+          sc[kt] = TAPCLIP_MFMA_16x16x32(kf, ql[t][s], sc[kt]);
         }
       }
     }
@@ -269,11 +269,11 @@ __global__ __launch_bounds__(512) void attn_kernel(AttnArgs a) {
       for (int dt = 0; dt < 4; ++dt) {
         const int coff = (pp << 5) + ((dt ^ sw) << 3);  // block pp, swizzled quad dt: columns 16 pp + 4 dt .. + 3
         const bf16x8_t vf = tr_pair(Vh + key0 * 128 + coff, Vh + key1 * 128 + coff);
-        oc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, ph, oc[dt], 0, 0, 0);
+        oc[dt] = TAPCLIP_MFMA_16x16x32(vf, ph, oc[dt]);
         if (SPLIT) {
           const bf16x8_t vfl = tr_pair(Vl + key0 * 128 + coff, Vl + key1 * 128 + coff);
-          oc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfl, ph, oc[dt], 0, 0, 0);
-          oc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pl, oc[dt], 0, 0, 0);
+          oc[dt] = TAPCLIP_MFMA_16x16x32(vfl, ph, oc[dt]);
+          oc[dt] = TAPCLIP_MFMA_16x16x32(vf, pl, oc[dt]);
         }
       }
     }
@@ -396,11 +396,11 @@ __global__ __launch_bounds__(512) void attn_flash_kernel(AttnArgs a) {
         for (int s = 0; s < 2; ++s) {
           const int off = kk * 128 + (((4 * s + g) ^ (kk & 7)) << 4);
           const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Kh + off);
-          sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qh[t][s], sc[kt], 0, 0, 0);
+          sc[kt] = TAPCLIP_MFMA_16x16x32(kf, qh[t][s], sc[kt]);
           if (SPLIT) {
             const bf16x8_t kfl = *reinterpret_cast<const bf16x8_t*>(Kl + off);
-            sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfl, qh[t][s], sc[kt], 0, 0, 0);
-            sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, ql[t][s], sc[kt], 0, 0, 0);
+            sc[kt] = TAPCLIP_MFMA_16x16x32(kfl, qh[t][s], sc[kt]);
+            sc[kt] = TAPCLIP_MFMA_16x16x32(kf, ql[t][s], sc[kt]);
           }
         }
       }
@@ -463,11 +463,11 @@ __global__ __launch_bounds__(512) void attn_flash_kernel(AttnArgs a) {
         for (int dt = 0; dt < 4; ++dt) {
           const int coff = (pp << 5) + ((dt ^ sw) << 3);
           const bf16x8_t vf = tr_pair(Vh + key0 * 128 + coff, Vh + key1 * 128 + coff);
-          oc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, ph, oc[t][dt], 0, 0, 0);
+          oc[t][dt] = TAPCLIP_MFMA_16x16x32(vf, ph, oc[t][dt]);
           if (SPLIT) {
             const bf16x8_t vfl = tr_pair(Vl + key0 * 128 + coff, Vl + key1 * 128 + coff);
-            oc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfl, ph, oc[t][dt], 0, 0, 0);
-            oc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pl, oc[t][dt], 0, 0, 0);
+            oc[t][dt] = TAPCLIP_MFMA_16x16x32(vfl, ph, oc[t][dt]);
+            oc[t][dt] = TAPCLIP_MFMA_16x16x32(vf, pl, oc[t][dt]);
           }
         }
       }

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = TAPCLIP_MFMA_16x16x32(wf[j], af[i], acc[j][i]);
     }
 
     TAPCLIP_STAGE_WRITE(cur ^ 1)  // the other buffer: its last readers passed the previous barrier

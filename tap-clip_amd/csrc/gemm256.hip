@@ -491,7 +491,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) acc[j][i] = TAPCLIP_MFMA_16x16x32(wf[j], af[i], acc[j][i]);
       if (!grp_b) wait_dma(issued);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");

@@ -33,7 +33,7 @@ class _Tower:
     def __init__(self, cfg: ClipDims, dims: TowerDims, state_dict: Dict[str, torch.Tensor], device, precision: str):
         if precision not in _lib.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {precision!r}")
-        self.lib = _lib.load()
+        self.lib = _lib.load("fp16" if precision == "fp16" else "bf16")
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("tapclip towers run on an AMD GPU only (device must be 'cuda[:i]'); there is no CPU path")
@@ -44,10 +44,13 @@ class _Tower:
             act=_lib.ACT_QUICK_GELU if cfg.quick_gelu else _lib.ACT_GELU_ERF, precision=_lib.PRECISIONS[precision],
         )
         h = C.c_void_p()
-        _lib.check(self.lib.tapclip_tower_create(C.byref(c), C.byref(h)))
+        self._check(self.lib.tapclip_tower_create(C.byref(c), C.byref(h)))
         self.handle = h
         self._ws: Optional[torch.Tensor] = None
         self._load(state_dict)
+
+    def _check(self, rc: int) -> None:
+        _lib.check(rc, self.lib)  # the error text lives in the library variant that produced it
 
     # -- weights -----------------------------------------------------------------------------
     def _wanted(self, key: str) -> Optional[str]:
@@ -62,9 +65,9 @@ class _Tower:
                     continue
                 d = _dev_f32(t, self.device)
                 shape = (C.c_int64 * max(d.dim(), 1))(*d.shape)
-                _lib.check(self.lib.tapclip_tower_load_weight(self.handle, name.encode(), _ptr(d), shape, d.dim(), stream))
+                self._check(self.lib.tapclip_tower_load_weight(self.handle, name.encode(), _ptr(d), shape, d.dim(), stream))
             torch.cuda.current_stream(self.device).synchronize()  # staging tensors may now be freed
-        _lib.check(self.lib.tapclip_tower_ready(self.handle))  # strict=True semantics
+        self._check(self.lib.tapclip_tower_ready(self.handle))  # strict=True semantics
 
     # -- scratch -----------------------------------------------------------------------------
     def workspace(self, n_seq: int, tokens: int) -> Tuple[torch.Tensor, int]:
@@ -76,12 +79,12 @@ class _Tower:
 
     # -- per-stage HIP-event timing ------------------------------------------------------------
     def profile(self, on: bool) -> None:
-        _lib.check(self.lib.tapclip_profile_enable(self.handle, int(on)))
+        self._check(self.lib.tapclip_profile_enable(self.handle, int(on)))
 
     def profile_read(self) -> Dict[str, Tuple[float, int]]:
         ms = (C.c_float * len(_lib.PROFILE_SLOTS))()
         n = (C.c_int64 * len(_lib.PROFILE_SLOTS))()
-        _lib.check(self.lib.tapclip_profile_read(self.handle, ms, n))
+        self._check(self.lib.tapclip_profile_read(self.handle, ms, n))
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(_lib.PROFILE_SLOTS)}
 
     def close(self) -> None:
@@ -117,7 +120,7 @@ class VisionTower(_Tower):
             return out
         with torch.cuda.device(self.device):
             ws, nbytes = self.workspace(B, self.cfg.n_tokens)
-            _lib.check(self.lib.tapclip_encode_image(self.handle, _ptr(x), B, _ptr(out), int(normalize), _ptr(ws),
+            self._check(self.lib.tapclip_encode_image(self.handle, _ptr(x), B, _ptr(out), int(normalize), _ptr(ws),
                                                      nbytes, _stream_ptr(self.device)))
         return out
 
@@ -129,7 +132,8 @@ class TextTower(_Tower):
     def __init__(self, cfg: ClipDims, state_dict, device="cuda", precision: str = "bf16"):
         # "fp8" is an image-tower precision (frozen weights, no backward: BASELINE.json configs[4]); the text
         # tower carries the prompt gradients and stays bf16 beside it
-        super().__init__(cfg, cfg.text, state_dict, device, "bf16" if precision == "fp8" else precision)
+        # ("fp16", IEEE-half operands, likewise: the text tower's gradients need bf16's exponent range)
+        super().__init__(cfg, cfg.text, state_dict, device, "bf16" if precision in ("fp8", "fp16") else precision)
 
     def _wanted(self, key):
         if key.startswith("transformer.resblocks.") or key in self._TOP:
@@ -152,7 +156,7 @@ class TextTower(_Tower):
         aout = mk(n, T, D) if want_attn_out else None
         with torch.cuda.device(self.device):
             ws, nbytes = self.workspace(n, T)
-            _lib.check(self.lib.tapclip_text_forward(self.handle, _ptr(xin), n, T, int(causal), _ptr(hidden), _ptr(heads),
+            self._check(self.lib.tapclip_text_forward(self.handle, _ptr(xin), n, T, int(causal), _ptr(hidden), _ptr(heads),
                                                      _ptr(mean), _ptr(aout), _ptr(ws), nbytes, _stream_ptr(self.device)))
         return {"hidden": hidden, "attn_heads": heads, "attn_mean": mean, "attn_out": aout}
 
@@ -165,7 +169,7 @@ class TextTower(_Tower):
         idx = None if index is None else index.to(device=self.device, dtype=torch.int64).contiguous()
         out = torch.empty(n, self.cfg.embed_dim, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.tapclip_text_pool_project(self.handle, _ptr(h), n, T, _ptr(idx), int(ln_final),
+            self._check(self.lib.tapclip_text_pool_project(self.handle, _ptr(h), n, T, _ptr(idx), int(ln_final),
                                                           int(normalize), _ptr(out), _stream_ptr(self.device)))
         return out
 
@@ -181,7 +185,7 @@ class TextTower(_Tower):
             if self._ws is None or self._ws.numel() < need:
                 self._ws = None
                 self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-            _lib.check(self.lib.tapclip_text_backward(self.handle, _ptr(xin), _ptr(g), n, T, int(causal), _ptr(out),
+            self._check(self.lib.tapclip_text_backward(self.handle, _ptr(xin), _ptr(g), n, T, int(causal), _ptr(out),
                                                       _ptr(self._ws), self._ws.numel(), _stream_ptr(self.device)))
         return out
 
@@ -194,7 +198,7 @@ class TextTower(_Tower):
         with torch.cuda.device(self.device):
             saved = torch.empty(int(self.lib.tapclip_text_saved_bytes(self.handle, n, T)), dtype=torch.uint8, device=self.device)
             ws, nbytes = self.workspace(n, T)
-            _lib.check(self.lib.tapclip_text_forward_saved(self.handle, _ptr(xin), n, T, int(causal), _ptr(hidden), _ptr(saved),
+            self._check(self.lib.tapclip_text_forward_saved(self.handle, _ptr(xin), n, T, int(causal), _ptr(hidden), _ptr(saved),
                                                            saved.numel(), _ptr(ws), nbytes, _stream_ptr(self.device)))
         return hidden, saved
 
@@ -205,7 +209,7 @@ class TextTower(_Tower):
         out = torch.empty_like(g)
         with torch.cuda.device(self.device):
             ws, nbytes = self.workspace(n, T)
-            _lib.check(self.lib.tapclip_text_backward_saved(self.handle, _ptr(saved), saved.numel(), _ptr(g), n, T, int(causal),
+            self._check(self.lib.tapclip_text_backward_saved(self.handle, _ptr(saved), saved.numel(), _ptr(g), n, T, int(causal),
                                                             _ptr(out), _ptr(ws), nbytes, _stream_ptr(self.device)))
         return out
 
@@ -216,7 +220,7 @@ class TextTower(_Tower):
         n, T, _ = h.shape
         out = torch.empty_like(h)
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.tapclip_text_pool_project_backward(self.handle, _ptr(h), n, T, int(normalize), _ptr(g),
+            self._check(self.lib.tapclip_text_pool_project_backward(self.handle, _ptr(h), n, T, int(normalize), _ptr(g),
                                                                    _ptr(out), _stream_ptr(self.device)))
         return out
 
@@ -227,7 +231,7 @@ class TextTower(_Tower):
         n, L = t.shape
         out = torch.empty(n, L, self.dims.width, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.tapclip_embed_tokens(self.handle, _ptr(t), n, L, int(add_pos), _ptr(out), _stream_ptr(self.device)))
+            self._check(self.lib.tapclip_embed_tokens(self.handle, _ptr(t), n, L, int(add_pos), _ptr(out), _stream_ptr(self.device)))
         return out
 
 

@@ -10,6 +10,8 @@ under open_clip's names so `state_dict()` / `load_state_dict()` keep the referen
 
 Extra keyword-only knobs (defaults keep behaviour):
   precision       "bf16" (fast) | "bf16x3" (split-bf16, ~fp32 accuracy: the parity mode) |
+                  "fp16" (image tower on the IEEE-half build of the same kernels: bf16 speed, 2.8e-4 embedding
+                  error; text tower bf16) |
                   "fp8" (image tower block GEMMs on MXFP8 MFMA, text tower bf16; a throughput mode:
                   ~4 % error per GEMM)
   attn_semantics  "intended": the text hook yields the head-mean softmax map [n,T,T] that the

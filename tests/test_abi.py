@@ -18,12 +18,13 @@ def _declared():
     return sorted(set(re.findall(r"\b(tapclip_[a-z0-9_]+)\s*\(", text)))
 
 
-def test_library_exports_every_declared_symbol():
-    lib = _lib.load()
+@pytest.mark.parametrize("variant", ["bf16", "fp16"])
+def test_library_exports_every_declared_symbol(variant):
+    lib = _lib.load(variant)  # libtapclip.so / libtapclip_fp16.so (the IEEE-half build of the same sources)
     names = _declared()
     assert len(names) >= 18
     for n in names:
-        assert hasattr(lib, n), f"libtapclip.so does not export {n}"
+        assert hasattr(lib, n), f"the {variant} library does not export {n}"
     assert sorted(s[0] for s in _lib.SYMBOLS) == names, "ctypes table and header disagree"
 
 
@@ -61,7 +62,10 @@ def test_tower_handle_lifecycle_without_gpu():
 
 
 def test_missing_library_is_a_hard_error(monkeypatch):
-    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_libs", {})
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libtapclip.so")
+    monkeypatch.setattr(_lib, "LIB_PATH_FP16", "/nonexistent/libtapclip_fp16.so")
     with pytest.raises(ImportError, match="no CPU fallback"):
         _lib.load()
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load("fp16")
