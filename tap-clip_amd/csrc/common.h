@@ -107,6 +107,9 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
   const float e = __builtin_amdgcn_exp2f(p * xc);
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
+// GELU of the 16-bit fast paths (bf16 and the IEEE-half build): the fit above.  (The erf form in the half build
+// changed nothing measurable -- cfg-1 logits 1.3e-3 -> 1.7e-3 rel-max, same 9.8e-4 rel-L2 -- and cost 40 us per c_fc.)
+__device__ __forceinline__ float gelu_fast16(float x) { return gelu_erf_fast(x); }
 // derivatives (backward of c_fc's activation); the bf16 forward uses the fitted GELU, whose derivative
 // differs from the exact one by < 2e-4
 __device__ __forceinline__ float gelu_erf_grad(float x) {

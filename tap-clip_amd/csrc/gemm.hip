@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
           // bf16 path: the fitted form (2.5e-5 abs, common.h), same as gemm256.hip so that a row's result
           // does not depend on the kernel / batch size; bf16x3 keeps the 5e-7 erf
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = SPLIT ? gelu_erf(v[e]) : gelu_erf_fast(v[e]);
+          for (int e = 0; e < 4; ++e) v[e] = SPLIT ? gelu_erf(v[e]) : gelu_fast16(v[e]);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = SPLIT ? gelu_quick(v[e]) : gelu_quick_fast(v[e]);

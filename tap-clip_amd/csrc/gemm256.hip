@@ -311,7 +311,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
           f32x4_t v = acc[j][i];
           if (EPI == EPI_BIAS_GELU_BF16) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ACT == 0 ? gelu_erf_fast(v[e]) : ACT == 1 ? gelu_quick_fast(v[e]) : v[e];
+            for (int e = 0; e < 4; ++e) v[e] = ACT == 0 ? gelu_fast16(v[e]) : ACT == 1 ? gelu_quick_fast(v[e]) : v[e];
           }
           const unsigned long long pk = (unsigned long long)pack_bf2(v[0], v[1]) | ((unsigned long long)pack_bf2(v[2], v[3]) << 32);
           const int chunk = 2 * j + (q >> 1);
@@ -357,8 +357,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
             f32x4_t v0 = acc[2 * J][i], v1 = acc[2 * J + 1][i];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              v0[e] = ACT == 0 ? gelu_erf_fast(v0[e]) : ACT == 1 ? gelu_quick_fast(v0[e]) : v0[e];
-              v1[e] = ACT == 0 ? gelu_erf_fast(v1[e]) : ACT == 1 ? gelu_quick_fast(v1[e]) : v1[e];
+              v0[e] = ACT == 0 ? gelu_fast16(v0[e]) : ACT == 1 ? gelu_quick_fast(v0[e]) : v0[e];
+              v1[e] = ACT == 0 ? gelu_fast16(v1[e]) : ACT == 1 ? gelu_quick_fast(v1[e]) : v1[e];
             }
             u32x4_t pk;
             pk[0] = pack_bf2(v0[0], v0[1]);
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
       if (EPI == EPI_BIAS_GELU_BF16) {
         if (g.act == 0) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = SPLIT ? gelu_erf(v[e]) : gelu_erf_fast(v[e]);  // see common.h
+          for (int e = 0; e < 4; ++e) v[e] = SPLIT ? gelu_erf(v[e]) : gelu_fast16(v[e]);  // see common.h
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = gelu_quick(v[e]);
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void splitk_fixup_kernel(GemmArgs g, int n_til
     v += *reinterpret_cast<const f32x4_t*>(g.split_ws + (size_t)(t * g.split_parts + p) * (BM * BN) + rr * BN + c4 * 4);
   if (EPI == EPI_BIAS_GELU_BF16) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = g.act == 0 ? gelu_erf_fast(v[e]) : gelu_quick(v[e]);
+    for (int e = 0; e < 4; ++e) v[e] = g.act == 0 ? gelu_fast16(v[e]) : gelu_quick(v[e]);
   }
   uint2 ph;
   ph.x = pack_bf2(v[0], v[1]);

@@ -129,11 +129,13 @@ class TextTower(_Tower):
     kind = _lib.TOWER_TEXT
     _TOP = ("token_embedding.weight", "positional_embedding", "ln_final.weight", "ln_final.bias", "text_projection")
 
-    def __init__(self, cfg: ClipDims, state_dict, device="cuda", precision: str = "bf16"):
+    def __init__(self, cfg: ClipDims, state_dict, device="cuda", precision: str = "bf16", inference_only: bool = False):
         # "fp8" is an image-tower precision (frozen weights, no backward: BASELINE.json configs[4]); the text
-        # tower carries the prompt gradients and stays bf16 beside it
-        # ("fp16", IEEE-half operands, likewise: the text tower's gradients need bf16's exponent range)
-        super().__init__(cfg, cfg.text, state_dict, device, "bf16" if precision in ("fp8", "fp16") else precision)
+        # tower carries the prompt gradients and stays bf16 beside it.  "fp16" (IEEE-half operands) likewise,
+        # unless the caller promises inference only: the gradients need bf16's exponent range, the forward does not.
+        if precision == "fp8" or (precision == "fp16" and not inference_only):
+            precision = "bf16"
+        super().__init__(cfg, cfg.text, state_dict, device, precision)
 
     def _wanted(self, key):
         if key.startswith("transformer.resblocks.") or key in self._TOP:

@@ -85,7 +85,7 @@ class _TextTransformer(_Bag):
         attn_mod = self.resblocks[-1].attn
         user_hooks = len(attn_mod._forward_hooks) > 0
         intended = own.attn_semantics == "intended"
-        r = own._text.forward(x, causal=causal, want_hidden=True, want_heads=user_hooks and intended,
+        r = own._text_now().forward(x, causal=causal, want_hidden=True, want_heads=user_hooks and intended,
                               want_mean=intended, want_attn_out=not intended)
         if intended:
             own.attention_maps.append(r["attn_mean"])               # [n, T, T]
@@ -111,7 +111,7 @@ class _ClipModel(_Bag):
     def encode_text(self, text: torch.Tensor, normalize: bool = False) -> torch.Tensor:
         own = self._owner
         x = own._text.embed_tokens(text, add_pos=True)
-        hidden = own._text.forward(x, causal=True)["hidden"]
+        hidden = own._text_now().forward(x, causal=True)["hidden"]
         return own._text.pool_project(hidden, index=text.argmax(dim=-1), ln_final=True, normalize=normalize)
 
 
@@ -185,6 +185,7 @@ class CLIPWrapper(nn.Module):
         # the HIP towers (weights packed to bf16 hi/lo inside the handles); strict=True semantics
         self._vision = engine.VisionTower(self.cfg, state_dict, dev, precision)
         self._text = engine.TextTower(self.cfg, state_dict, dev, precision)
+        self._make_text_eval(state_dict, dev)
 
         # a later load_state_dict (reference test_cross_domain.py:61 loads `clip.model.*` back with
         # strict=False) must also reach the packed copies inside the HIP handles
@@ -214,6 +215,15 @@ class CLIPWrapper(nn.Module):
                 node = node._modules[name]
             node.register_parameter(parts[-1], nn.Parameter(t.detach().to(dev, torch.float32), requires_grad=False))
 
+    def _make_text_eval(self, state_dict, dev) -> None:
+        """precision "fp16": forwards without autograd run on a second, IEEE-half text tower (logits inside the 1e-3
+        bound at full speed); anything that is differentiated keeps the bf16 tower (`_text`)."""
+        self._text_eval = (engine.TextTower(self.cfg, state_dict, dev, "fp16", inference_only=True)
+                           if self.precision == "fp16" else self._text)
+
+    def _text_now(self):
+        return self._text if torch.is_grad_enabled() else self._text_eval
+
     @staticmethod
     def _note_incoming_weights(module, state_dict, prefix, *args):
         module._reload_pending = any(k.startswith(prefix + "model.") for k in state_dict)
@@ -226,6 +236,7 @@ class CLIPWrapper(nn.Module):
             dev = torch.device(module.device)
             module._vision = engine.VisionTower(module.cfg, sd, dev, module.precision)
             module._text = engine.TextTower(module.cfg, sd, dev, module.precision)
+            module._make_text_eval(sd, dev)
             module.weights_version += 1
 
     # ---- reference surface -----------------------------------------------------------------

@@ -450,7 +450,9 @@ def test_fullmodel_vitb32_cfg1_vs_reference(semantics):
     """BASELINE.json configs[0]: ViT-B/32, batch 8, 10 classes, P=5 -- the reference FullModel's own logits."""
     g = golden(f"fullmodel_{semantics}_vitb32")
     ref = torch.from_numpy(g["logits"])
-    for precision, tol in (("bf16x3", TOL), ("bf16", TOL_BF16)):
+    # fp16: both towers on the IEEE-half build for this no-grad forward: 9.8e-4 rel-L2 / 1.3e-3 rel-max on these
+    # small-magnitude logits (bf16: 1.4e-2 / 2.0e-2), bound 2e-3; the embeddings themselves are at 2.8e-4
+    for precision, tol in (("bf16x3", TOL), ("bf16", TOL_BF16), ("fp16", 2 * TOL)):
         model, images = _build_full("ViT-B-32", g, semantics, precision)
         with torch.no_grad():
             out = model(images, torch.from_numpy(g["labels"]).to(DEV))
