@@ -181,6 +181,8 @@ def block_forward(
         taps["mlp_hidden"] = h
     h = F.linear(_rq(h, emulate), _rq(g("mlp.c_proj.weight"), emulate), g("mlp.c_proj.bias"))
     x = x + _rb(h, emulate)
+    if emulate == "mx8":
+        x = _rb(x, emulate)  # the fp8 path keeps the residual stream of the blocks in 16 bits (written once per block)
     if taps is not None:
         taps["out"] = x
     return x, (p if want_probs else None)
@@ -235,6 +237,8 @@ def encode_image(images: torch.Tensor, sd: Dict[str, torch.Tensor], cfg: ClipDim
     x = torch.cat([cls, x], dim=1)
     x = x + sd["visual.positional_embedding"]
     x = F.layer_norm(x, (width,), sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"], 1e-5)
+    if emulate == "mx8":
+        x = _rb(x, emulate)
     x, _, _ = transformer_forward(x, sd, "visual.transformer.", cfg.vision.layers, cfg.vision.heads,
                                   None, cfg.quick_gelu, emulate)
     pooled = F.layer_norm(x[:, 0], (width,), sd["visual.ln_post.weight"], sd["visual.ln_post.bias"], 1e-5)

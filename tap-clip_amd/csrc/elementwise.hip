@@ -300,6 +300,15 @@ __global__ void add_delta_kernel(float* __restrict__ x, const bf16_t* __restrict
   x[i] = t;
 }
 
+__global__ void gather_cls16_kernel(const bf16_t* __restrict__ x16, const bf16_t* __restrict__ delta, int tokens, int D, int64_t total,
+                                    float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t b = i / D;
+  const int64_t src = b * tokens * (int64_t)D + (i - b * D);
+  out[i] = bf2f(x16[src]) + (delta ? bf2f(delta[src]) : 0.f);
+}
+
 inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
 }  // namespace
@@ -351,6 +360,12 @@ hipError_t launch_pool_project(const float* src, const bf16_t* dhi, const bf16_t
     case 3: hipLaunchKernelGGL((pool_project_kernel<3>), grid, block, sh, s, src, dhi, dlo, tokens, K, index, fixed_token, ln_g, ln_b, proj, E, normalize, out); break;
     default: hipLaunchKernelGGL((pool_project_kernel<4>), grid, block, sh, s, src, dhi, dlo, tokens, K, index, fixed_token, ln_g, ln_b, proj, E, normalize, out); break;
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_cls16(const bf16_t* x16, const bf16_t* delta, int32_t B, int32_t tokens, int32_t D, float* out, hipStream_t s) {
+  const int64_t total = (int64_t)B * D;
+  hipLaunchKernelGGL(gather_cls16_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, x16, delta, tokens, D, total, out);
   return hipGetLastError();
 }
 

@@ -85,9 +85,12 @@ hipError_t launch_add_layernorm(float* x, const bf16_t* delta_hi, const bf16_t* 
 hipError_t launch_add_layernorm_ex(int add, float* x, const bf16_t* d1_hi, const bf16_t* d1_lo, const bf16_t* d2_hi,
                                    const bf16_t* d2_lo, const float* gamma, const float* beta, int64_t rows, int32_t d,
                                    bf16_t* out_hi, bf16_t* out_lo, hipStream_t s);
-// LayerNorm with MXFP8 output: out_q [rows, d] e4m3 + out_sc [d/64][rows_pad][2]; add = 0 (none) or as above
-hipError_t launch_layernorm_mx8(int add, float* x, const bf16_t* d1_hi, const bf16_t* d2_hi, const float* gamma, const float* beta,
-                                int64_t rows, int32_t d, uint8_t* out_q, uint8_t* out_sc, int64_t rows_pad, hipStream_t s);
+// LayerNorm with MXFP8 output: out_q [rows, d] e4m3 + out_sc [d/64][rows_pad][2]; add = 0 (none) or as above.
+// x16 != nullptr: the residual stream is 16-bit ([rows, d]) and x is ignored.
+hipError_t launch_layernorm_mx8(int add, float* x, bf16_t* x16, const bf16_t* d1_hi, const bf16_t* d2_hi, const float* gamma,
+                                const float* beta, int64_t rows, int32_t d, uint8_t* out_q, uint8_t* out_sc, int64_t rows_pad, hipStream_t s);
+// out[b, :] = x16[b * tokens, :] + delta[b * tokens, :]  (the CLS rows of a 16-bit residual stream, as fp32 [B, D])
+hipError_t launch_gather_cls16(const bf16_t* x16, const bf16_t* delta, int32_t B, int32_t tokens, int32_t D, float* out, hipStream_t s);
 // x[i] += delta_hi[i] (+ delta_lo[i])
 hipError_t launch_add_delta(float* x, const bf16_t* delta_hi, const bf16_t* delta_lo, int64_t n, hipStream_t s);
 

@@ -14,8 +14,10 @@ namespace {
 //   1  x += d1, written back            2  x + d1 normalised, x NOT written back (LN2: saves 4 of 12 B/element)
 //   3  x += d1 + d2, written back       (the next block's LN1 then folds both branches: 14 B/element; a block's two
 //                                        LayerNorms move 22 B/element instead of 24)
-template <int MODE, int NV, int ADD>  // NV float4 per lane: d = 256 * NV
-__global__ __launch_bounds__(256) void ln_vec_kernel(float* __restrict__ x, int64_t ldx,
+// XH: the residual stream itself is 16-bit (x16, row stride d) instead of fp32 x -- the fp8 precision only, where
+// a 2^-9 rounding of x per block is far below the MXFP8 operand error and the LayerNorms are 20 % of the step.
+template <int MODE, int NV, int ADD, bool XH = false>  // NV float4 per lane: d = 256 * NV
+__global__ __launch_bounds__(256) void ln_vec_kernel(float* __restrict__ x, int64_t ldx, bf16_t* __restrict__ x16,
                                                      const bf16_t* __restrict__ d_hi, const bf16_t* __restrict__ d_lo,
                                                      const bf16_t* __restrict__ e_hi, const bf16_t* __restrict__ e_lo,
                                                      const float* __restrict__ gamma,
@@ -25,13 +27,18 @@ __global__ __launch_bounds__(256) void ln_vec_kernel(float* __restrict__ x, int6
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  float* xr = x + row * ldx;
+  float* xr = XH ? nullptr : x + row * ldx;
   float4 v[NV];
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int c = 4 * lane + 256 * j;
-    v[j] = *reinterpret_cast<const float4*>(xr + c);
+    if (XH) {
+      const uint2 h = *reinterpret_cast<const uint2*>(x16 + row * d + c);
+      v[j] = make_float4(bf2f((bf16_t)(h.x & 0xFFFF)), bf2f((bf16_t)(h.x >> 16)), bf2f((bf16_t)(h.y & 0xFFFF)), bf2f((bf16_t)(h.y >> 16)));
+    } else {
+      v[j] = *reinterpret_cast<const float4*>(xr + c);
+    }
     if (ADD) {
       auto add4 = [&](const bf16_t* p) {
         const uint2 h = *reinterpret_cast<const uint2*>(p + row * d + c);
@@ -44,7 +51,10 @@ __global__ __launch_bounds__(256) void ln_vec_kernel(float* __restrict__ x, int6
         add4(e_hi);
         if (e_lo != nullptr) add4(e_lo);
       }
-      if (ADD != 2) *reinterpret_cast<float4*>(xr + c) = v[j];
+      if (ADD != 2) {
+        if (XH) *reinterpret_cast<uint2*>(x16 + row * d + c) = make_uint2(pack_bf2(v[j].x, v[j].y), pack_bf2(v[j].z, v[j].w));
+        else *reinterpret_cast<float4*>(xr + c) = v[j];
+      }
     }
     s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
   }
@@ -152,14 +162,28 @@ __global__ __launch_bounds__(256) void ln_generic_kernel(float* __restrict__ x, 
 template <int MODE, int ADD>
 hipError_t launch_mode(float* x, int64_t ldx, const bf16_t* dh, const bf16_t* dl, const bf16_t* eh, const bf16_t* el, const float* gamma,
                        const float* beta, int64_t rows, int32_t d, bf16_t* hi, bf16_t* lo, float* f32, hipStream_t s, uint8_t* q = nullptr,
-                       uint8_t* qs = nullptr, int64_t rows_pad = 0) {
+                       uint8_t* qs = nullptr, int64_t rows_pad = 0, bf16_t* x16 = nullptr) {
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (x16 != nullptr) {  // 16-bit residual stream: MXFP8 output only
+    if constexpr (MODE == 3) {
+      if (d % 256 != 0 || d / 256 > 4) return hipErrorInvalidValue;
+      switch (d / 256) {
+        case 1: hipLaunchKernelGGL((ln_vec_kernel<3, 1, ADD, true>), grid, block, 0, s, nullptr, 0, x16, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+        case 2: hipLaunchKernelGGL((ln_vec_kernel<3, 2, ADD, true>), grid, block, 0, s, nullptr, 0, x16, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+        case 3: hipLaunchKernelGGL((ln_vec_kernel<3, 3, ADD, true>), grid, block, 0, s, nullptr, 0, x16, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+        default: hipLaunchKernelGGL((ln_vec_kernel<3, 4, ADD, true>), grid, block, 0, s, nullptr, 0, x16, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+      }
+      return hipGetLastError();
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   if (d % 256 == 0 && d / 256 <= 4 && ldx % 4 == 0) {
     switch (d / 256) {
-      case 1: hipLaunchKernelGGL((ln_vec_kernel<MODE, 1, ADD>), grid, block, 0, s, x, ldx, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
-      case 2: hipLaunchKernelGGL((ln_vec_kernel<MODE, 2, ADD>), grid, block, 0, s, x, ldx, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
-      case 3: hipLaunchKernelGGL((ln_vec_kernel<MODE, 3, ADD>), grid, block, 0, s, x, ldx, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
-      default: hipLaunchKernelGGL((ln_vec_kernel<MODE, 4, ADD>), grid, block, 0, s, x, ldx, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+      case 1: hipLaunchKernelGGL((ln_vec_kernel<MODE, 1, ADD>), grid, block, 0, s, x, ldx, nullptr, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+      case 2: hipLaunchKernelGGL((ln_vec_kernel<MODE, 2, ADD>), grid, block, 0, s, x, ldx, nullptr, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+      case 3: hipLaunchKernelGGL((ln_vec_kernel<MODE, 3, ADD>), grid, block, 0, s, x, ldx, nullptr, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+      default: hipLaunchKernelGGL((ln_vec_kernel<MODE, 4, ADD>), grid, block, 0, s, x, ldx, nullptr, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
     }
   } else {
     if constexpr (MODE == 3) return hipErrorInvalidValue;  // MXFP8 output: widths 256 .. 1024 only
@@ -171,12 +195,12 @@ hipError_t launch_mode(float* x, int64_t ldx, const bf16_t* dh, const bf16_t* dl
 template <int MODE>
 hipError_t launch_add_mode(int add, float* x, const bf16_t* dh, const bf16_t* dl, const bf16_t* eh, const bf16_t* el, const float* gamma,
                            const float* beta, int64_t rows, int32_t d, bf16_t* hi, bf16_t* lo, hipStream_t s, uint8_t* q = nullptr,
-                           uint8_t* qs = nullptr, int64_t rows_pad = 0) {
+                           uint8_t* qs = nullptr, int64_t rows_pad = 0, bf16_t* x16 = nullptr) {
   switch (add) {
-    case 0: return launch_mode<MODE, 0>(x, d, nullptr, nullptr, nullptr, nullptr, gamma, beta, rows, d, hi, lo, nullptr, s, q, qs, rows_pad);
-    case 1: return launch_mode<MODE, 1>(x, d, dh, dl, nullptr, nullptr, gamma, beta, rows, d, hi, lo, nullptr, s, q, qs, rows_pad);
-    case 2: return launch_mode<MODE, 2>(x, d, dh, dl, nullptr, nullptr, gamma, beta, rows, d, hi, lo, nullptr, s, q, qs, rows_pad);
-    case 3: return launch_mode<MODE, 3>(x, d, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, nullptr, s, q, qs, rows_pad);
+    case 0: return launch_mode<MODE, 0>(x, d, nullptr, nullptr, nullptr, nullptr, gamma, beta, rows, d, hi, lo, nullptr, s, q, qs, rows_pad, x16);
+    case 1: return launch_mode<MODE, 1>(x, d, dh, dl, nullptr, nullptr, gamma, beta, rows, d, hi, lo, nullptr, s, q, qs, rows_pad, x16);
+    case 2: return launch_mode<MODE, 2>(x, d, dh, dl, nullptr, nullptr, gamma, beta, rows, d, hi, lo, nullptr, s, q, qs, rows_pad, x16);
+    case 3: return launch_mode<MODE, 3>(x, d, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, nullptr, s, q, qs, rows_pad, x16);
     default: return hipErrorInvalidValue;
   }
 }
@@ -209,11 +233,11 @@ hipError_t launch_add_layernorm_ex(int add, float* x, const bf16_t* d1_hi, const
 
 // MXFP8 output (the A operand of the fp8 path's QKV / c_fc GEMMs): out_q [rows, d] e4m3, out_sc [d/64][rows_pad][2].
 // add: 0 = plain LayerNorm; 1, 2, 3 as launch_add_layernorm_ex.
-hipError_t launch_layernorm_mx8(int add, float* x, const bf16_t* d1_hi, const bf16_t* d2_hi, const float* gamma, const float* beta,
-                                int64_t rows, int32_t d, uint8_t* out_q, uint8_t* out_sc, int64_t rows_pad, hipStream_t s) {
-  if (rows <= 0 || d <= 0 || d % 256 != 0 || d > 1024 || rows_pad < rows || !out_q || !out_sc) return hipErrorInvalidValue;
+hipError_t launch_layernorm_mx8(int add, float* x, bf16_t* x16, const bf16_t* d1_hi, const bf16_t* d2_hi, const float* gamma,
+                                const float* beta, int64_t rows, int32_t d, uint8_t* out_q, uint8_t* out_sc, int64_t rows_pad, hipStream_t s) {
+  if (rows <= 0 || d <= 0 || d % 256 != 0 || d > 1024 || rows_pad < rows || !out_q || !out_sc || (!x && !x16)) return hipErrorInvalidValue;
   if ((add >= 1 && d1_hi == nullptr) || (add == 3 && d2_hi == nullptr)) return hipErrorInvalidValue;
-  return launch_add_mode<3>(add, x, d1_hi, nullptr, d2_hi, nullptr, gamma, beta, rows, d, nullptr, nullptr, s, out_q, out_sc, rows_pad);
+  return launch_add_mode<3>(add, x, d1_hi, nullptr, d2_hi, nullptr, gamma, beta, rows, d, nullptr, nullptr, s, out_q, out_sc, rows_pad, x16);
 }
 
 }  // namespace tapclip

@@ -111,6 +111,7 @@ struct Workspace {
   // fp8 precision: MXFP8 activations live in the front of the bf16 buffers they replace (e4m3 [M, K] then the
   // scales [K/64][m_pad][2]: 1.03 bytes per element against 2)
   uint8_t *xn_q = nullptr, *xn_s = nullptr, *ao_q = nullptr, *ao_s = nullptr, *h_q = nullptr, *h_s = nullptr;
+  bf16_t* x16 = nullptr;  // fp8 precision: the residual stream of the blocks is 16-bit
   int64_t m_pad = 0;
   size_t bytes = 0;
 };
@@ -157,6 +158,7 @@ Workspace carve(const tapclip_tower* t, int64_t n_seq, int tokens, void* base) {
     view(w.xn_hi, D, w.xn_q, w.xn_s);
     view(w.ao_hi, D, w.ao_q, w.ao_s);
     view(w.h_hi, F, w.h_q, w.h_s);
+    w.x16 = static_cast<bf16_t*>(take(M * D * 2));
   }
   w.bytes = off;
   return w;
@@ -283,7 +285,7 @@ int gemm_mx8(tapclip_tower* t, int slot, int epi, const uint8_t* a_q, const uint
 // block-scaled MXFP8 MFMA.  Their A operands are quantised where they are produced -- LayerNorm (layernorm.hip
 // MODE 3), the attention core's output (attention.hip store_o_mx8), the GELU epilogue of c_fc (gemm_mx8.hip) --
 // q|k|v and the two residual branches stay bf16, the residual stream fp32.
-int run_blocks_fp8(tapclip_tower* t, float* x, int64_t n_seq, int tokens, const Workspace& w, hipStream_t s) {
+int run_blocks_fp8(tapclip_tower* t, int64_t n_seq, int tokens, const Workspace& w, hipStream_t s) {
   const int64_t M = n_seq * tokens;
   const int D = t->cfg.width, F = t->cfg.mlp_dim, H = t->cfg.heads;
   int rc;
@@ -292,7 +294,7 @@ int run_blocks_fp8(tapclip_tower* t, float* x, int64_t n_seq, int tokens, const 
     {
       ProfScope ps(t, 1, s);
       // block l > 0: x still lacks BOTH branches of block l - 1 (its LN2 did not write x back)
-      HIP_TRY(launch_layernorm_mx8(li == 0 ? 0 : 3, x, w.a_hi, w.d_hi, L.ln1_g, L.ln1_b, M, D, w.xn_q, w.xn_s, w.m_pad, s));
+      HIP_TRY(launch_layernorm_mx8(li == 0 ? 0 : 3, nullptr, w.x16, w.a_hi, w.d_hi, L.ln1_g, L.ln1_b, M, D, w.xn_q, w.xn_s, w.m_pad, s));
     }
     if ((rc = gemm_mx8(t, 2, EPI_BIAS_BF16, w.xn_q, w.xn_s, w.m_pad, L.qqkv, L.bqkv, M, 3 * D, D, w.qkv_hi, nullptr, nullptr, s))) return rc;
     {
@@ -309,7 +311,7 @@ int run_blocks_fp8(tapclip_tower* t, float* x, int64_t n_seq, int tokens, const 
     {
       ProfScope ps(t, 1, s);
       // the last block folds out_proj's branch into x here, so that only c_proj's is pending on return
-      HIP_TRY(launch_layernorm_mx8(li == t->cfg.layers - 1 ? 1 : 2, x, w.a_hi, nullptr, L.ln2_g, L.ln2_b, M, D, w.xn_q, w.xn_s, w.m_pad, s));
+      HIP_TRY(launch_layernorm_mx8(li == t->cfg.layers - 1 ? 1 : 2, nullptr, w.x16, w.a_hi, nullptr, L.ln2_g, L.ln2_b, M, D, w.xn_q, w.xn_s, w.m_pad, s));
     }
     if ((rc = gemm_mx8(t, 5, EPI_BIAS_GELU_MX8, w.xn_q, w.xn_s, w.m_pad, L.qfc, L.bfc, M, F, D, nullptr, w.h_q, w.h_s, s))) return rc;
     if ((rc = gemm_mx8(t, 6, EPI_BIAS_BF16, w.h_q, w.h_s, w.m_pad, L.qpr, L.bpr, M, D, F, w.d_hi, nullptr, nullptr, s))) return rc;
@@ -679,14 +681,21 @@ int tapclip_encode_image(tapclip_tower_t* t, const float* images, int32_t B, flo
   }
   {
     ProfScope ps(t, 1, s);
-    HIP_TRY(launch_layernorm(w.x, D, t->lnpre_g, t->lnpre_b, (int64_t)B * N, D, nullptr, nullptr, w.x, s));
+    // (fp8: ln_pre writes the blocks' 16-bit residual stream; else it normalises the fp32 stream in place)
+    if (t->fp8) HIP_TRY(launch_layernorm(w.x, D, t->lnpre_g, t->lnpre_b, (int64_t)B * N, D, w.x16, nullptr, nullptr, s));
+    else HIP_TRY(launch_layernorm(w.x, D, t->lnpre_g, t->lnpre_b, (int64_t)B * N, D, nullptr, nullptr, w.x, s));
   }
-  rc = t->fp8 ? run_blocks_fp8(t, w.x, B, N, w, s) : run_blocks(t, w.x, B, N, 0, w, nullptr, nullptr, s);
+  rc = t->fp8 ? run_blocks_fp8(t, B, N, w, s) : run_blocks(t, w.x, B, N, 0, w, nullptr, nullptr, s);
   if (rc) return rc;
   {
     ProfScope ps(t, 7, s);
     // the last c_proj branch is still pending: the pool kernel adds it to the CLS rows it gathers
-    HIP_TRY(launch_pool_project(w.x, w.d_hi, w.d_lo, B, N, D, nullptr, 0, t->lnpost_g, t->lnpost_b, t->proj, t->cfg.embed_dim, normalize, out, s));
+    if (t->fp8) {
+      HIP_TRY(launch_gather_cls16(w.x16, w.d_hi, B, N, D, w.x, s));  // [B, D] fp32 at the front of the (now free) fp32 buffer
+      HIP_TRY(launch_pool_project(w.x, nullptr, nullptr, B, 1, D, nullptr, 0, t->lnpost_g, t->lnpost_b, t->proj, t->cfg.embed_dim, normalize, out, s));
+    } else {
+      HIP_TRY(launch_pool_project(w.x, w.d_hi, w.d_lo, B, N, D, nullptr, 0, t->lnpost_g, t->lnpost_b, t->proj, t->cfg.embed_dim, normalize, out, s));
+    }
   }
   return TAPCLIP_OK;
 }
