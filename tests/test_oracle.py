@@ -191,3 +191,47 @@ def test_emulated_bf16_oracle_is_close_to_fp32():
     a = clip_ref.encode_image(images, sd, cfg, normalize=True)
     b = clip_ref.encode_image(images, sd, cfg, emulate="bf16", normalize=True)
     assert 1e-5 < rel_l2(b, a) < 3e-2
+
+
+# ---- MXFP8 restatement (oracle/mx8_ref.py): properties the OCP MX v1.0 conversion must have -------------------
+def test_mx8_restatement_properties():
+    from oracle import mx8_ref
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(64, 256, generator=g) * torch.exp2(torch.randint(-20, 20, (64, 8, 1), generator=g).float()).repeat_interleave(32, 1).reshape(64, 256)
+    x[0, :32] = 0.0
+    q, s = mx8_ref.quantize(x)
+    assert q.dtype == torch.uint8 and s.dtype == torch.uint8 and q.shape == (64, 256) and s.shape == (64, 8)
+    assert not bool(((q & 0x7F) == 0x7F).any()), "no NaN encodings"
+    d = mx8_ref.dequantize(q, s)
+    xb, db = x.reshape(64, 8, 32), d.reshape(64, 8, 32)
+    amax = xb.abs().amax(-1, keepdim=True)
+    # shared scale 2^(floor(log2 amax) - 8): the scaled block maximum lands in [256, 512) and saturates at 448 (an
+    # error of at most 64/512 of it); every other element is within half an e4m3 step, at most 16/256 of the maximum
+    assert bool(((xb - db).abs() <= amax * 0.125 + 1e-30).all())
+    assert float(((xb - db).norm(dim=-1) / xb.norm(dim=-1).clamp_min(1e-30)).max()) < 0.08
+    assert bool((db[0, 0] == 0).all()) and int(s[0, 0]) == 0
+    # exactly representable inputs survive
+    e = torch.tensor([[1.0, -2.0, 0.5, 448.0] * 8])
+    assert torch.equal(mx8_ref.dequantize(*mx8_ref.quantize(e)), e)
+    # k-step-major scale layout round trip (include/tapclip.h tapclip_mx8_quantize)
+    t = mx8_ref.scales_to_kstep_major(s, 72)
+    assert t.shape == (4, 72, 2) and torch.equal(mx8_ref.scales_from_kstep_major(t, 64), s)
+    assert int(t[1, 5, 0]) == int(s[5, 2]) and int(t[1, 5, 1]) == int(s[5, 3])
+    # idempotent: quantising the dequantised tensor reproduces the same bytes
+    q2, s2 = mx8_ref.quantize(d)
+    assert torch.equal(q2, q) and torch.equal(s2[db.abs().amax(-1) > 0], s[db.abs().amax(-1) > 0])
+
+
+def test_oracle_mx8_and_fp16_emulation_modes_run():
+    cfg = clip_ref.CONFIGS["tiny"]
+    import tap_clip_amd  # noqa: F401
+    from tap_clip_amd import synth
+    sd = synth.make_state_dict(__import__("tap_clip_amd").configs.get_config("tiny"), seed=2, text=False)
+    images = synth.make_images(2, __import__("tap_clip_amd").configs.get_config("tiny"), 3)
+    with torch.no_grad():
+        ref = clip_ref.encode_image(images, sd, cfg)
+        for mode, bound in (("fp16", 2e-3), ("bf16", 2e-2), ("mx8", 0.2)):
+            out = clip_ref.encode_image(images, sd, cfg, emulate=mode)
+            err = float((out - ref).norm() / ref.norm())
+            assert 0 < err < bound, (mode, err)
