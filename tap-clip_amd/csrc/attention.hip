@@ -75,7 +75,7 @@ __device__ __forceinline__ void store_o_mx8(const AttnArgs& a, const f32x4_t (&o
   for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
     for (int e = 0; e < 4; ++e) am = fmaxf(am, fabsf(oc[dt][e] * inv));
-  am = fmaxf(am, __shfl_xor(am, 16, 64));
+  am = xor16_max(am);
   const uint32_t byte = mx8_scale_byte(am);
   if (!valid) return;
   const float is = mx8_inv_scale(byte);
@@ -209,8 +209,7 @@ __global__ __launch_bounds__(512) void attn_kernel(AttnArgs a) {
       }
       mx = fmaxf(mx, fmaxf(fmaxf(sc[kt][0], sc[kt][1]), fmaxf(sc[kt][2], sc[kt][3])));
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = rows_max(mx);
     const float LOG2E = 1.44269504088896340736f;
     const float nmx = -mx * LOG2E;
     float sum = 0.f;
@@ -222,8 +221,7 @@ __global__ __launch_bounds__(512) void attn_kernel(AttnArgs a) {
         sc[kt][e] = p;
         sum += p;
       }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    sum = rows_sum(sum);
     const float inv = 1.0f / sum;
 
     // ---- optional probability write-back: probs[seq, head, q, key]
@@ -416,8 +414,7 @@ __global__ __launch_bounds__(512) void attn_flash_kernel(AttnArgs a) {
         }
         bm = fmaxf(bm, fmaxf(fmaxf(sc[kt][0], sc[kt][1]), fmaxf(sc[kt][2], sc[kt][3])));
       }
-      bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
-      bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+      bm = rows_max(bm);
       const float m_new = fmaxf(m[t], bm);
       // m_new == -inf only while every key so far is masked (then p = 0 and nothing is accumulated)
       const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f((m[t] - m_new) * LOG2E);
@@ -479,8 +476,7 @@ __global__ __launch_bounds__(512) void attn_flash_kernel(AttnArgs a) {
     if (qt0 + t >= n_qt) break;
     const int qi = (qt0 + t) * 16 + r;
     float sum = l[t];
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    sum = rows_sum(sum);
     const float inv = 1.0f / sum;
     if (!SPLIT && a.out_q != nullptr) store_o_mx8(a, oc[t], inv, row0 + qi, head, g, qi < T);
     else if (qi < T) store_o_bf16<SPLIT>(a, oc[t], inv, row0 + qi, head, g);

@@ -69,6 +69,28 @@ __device__ __forceinline__ void split_bf(float x, bf16_t& hi, bf16_t& lo) {
   lo = f2bf(x - bf2f(hi));
 }
 
+// Reductions over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (one per 16-lane row) on the VALU: v_permlane16_swap /
+// v_permlane32_swap of (x, x) leave row pairs (halves) of x in the two results, so one max / add finishes an xor
+// step -- no LDS round trip (__shfl_xor lowers to ds_bpermute_b32: ~100 cycles, four of them in sequence per softmax row).
+__device__ __forceinline__ float xor16_max(float x) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor16_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float rows_max(float x) { return xor32_max(xor16_max(x)); }
+__device__ __forceinline__ float rows_sum(float x) { return xor32_sum(xor16_sum(x)); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
