@@ -172,3 +172,22 @@ def test_fp8_text_tower_stays_bf16(eng):
     assert t.precision == "bf16"
     with pytest.raises(ValueError):
         eng.VisionTower(cfg, sd, DEV, "fp8")  # width 128: the MXFP8 GEMM needs width % 256 == 0
+
+
+@pytest.mark.parametrize("precision", ["fp8", "fp16"])
+def test_full_batch_properties_other_precisions(eng, precision):
+    """BASELINE configs[1] size (batch 256) in the fp8 and fp16 precisions: finite, unit norms, run-to-run identical,
+    and an image's embedding does not depend on its batch mates (rows outside a K-split tail: bit-identical)."""
+    from tap_clip_amd import configs, synth
+    cfg = configs.get_config("ViT-B-16")
+    sd = synth.make_state_dict(cfg, seed=2, text=False)
+    tower = eng.VisionTower(cfg, sd, DEV, precision)
+    images = synth.make_images(256, cfg, 0).to(DEV)
+    a = tower.encode_image(images, normalize=True)
+    assert torch.equal(a, tower.encode_image(images, normalize=True))
+    assert torch.isfinite(a).all()
+    assert torch.allclose(a.norm(dim=-1), torch.ones(256, device=DEV), atol=1e-5)
+    small = tower.encode_image(images[:8].clone(), normalize=True)
+    assert torch.equal(small, a[:8])
+    last = tower.encode_image(images[-8:].clone(), normalize=True)
+    assert float((last - a[-8:]).norm() / a[-8:].norm()) < (2e-3 if precision == "fp16" else 5e-2)
