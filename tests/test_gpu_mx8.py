@@ -191,3 +191,33 @@ def test_full_batch_properties_other_precisions(eng, precision):
     assert torch.equal(small, a[:8])
     last = tower.encode_image(images[-8:].clone(), normalize=True)
     assert float((last - a[-8:]).norm() / a[-8:].norm()) < (2e-3 if precision == "fp16" else 5e-2)
+
+
+def test_fp8_flash_attention_path_vit_l14_geometry(eng):
+    """ViT-L/14@336 geometry (577 tokens, d = 1024, 16 heads), one block, fp8: the flash-style attention kernel's
+    MXFP8 store path, against the oracle with MXFP8 rounding at the same points and against the fp32 oracle."""
+    from oracle import clip_ref
+    from tap_clip_amd import configs, synth
+    d, heads, mlp = 1024, 16, 4096
+    cfg = configs.ClipDims("blk8l", 64, 336, 14, configs.TowerDims(d, 1, heads, mlp), configs.TowerDims(128, 1, 2, 256), vocab=16, ctx=8)
+    sd = {}
+    synth._tower(sd, "visual.transformer.", d, 1, mlp, seed=9)
+    g = torch.Generator().manual_seed(9)
+    sd["visual.conv1.weight"] = torch.randn(d, 3, 14, 14, generator=g) * 0.03
+    sd["visual.class_embedding"] = torch.randn(d, generator=g) * 0.3
+    sd["visual.positional_embedding"] = torch.randn(577, d, generator=g) * 0.3
+    for k in ("ln_pre", "ln_post"):
+        sd[f"visual.{k}.weight"] = 1.0 + 0.1 * torch.randn(d, generator=g)
+        sd[f"visual.{k}.bias"] = 0.05 * torch.randn(d, generator=g)
+    sd["visual.proj"] = torch.randn(d, 64, generator=g) * d ** -0.5
+    tower = eng.VisionTower(cfg, sd, DEV, "fp8")
+    images = synth.make_images(3, cfg, 11)
+    got = tower.encode_image(images.to(DEV)).cpu()
+    ocfg = clip_ref.ClipDims("blk8l", 64, 336, 14, clip_ref.TowerDims(d, 1, heads, mlp), clip_ref.TowerDims(128, 1, 2, 256), vocab=16, ctx=8)
+    with torch.no_grad():
+        emu = clip_ref.encode_image(images, sd, ocfg, emulate="mx8")
+        ref = clip_ref.encode_image(images, sd, ocfg)
+    e_emu = float((got - emu).norm() / emu.norm())
+    e_ref = float((got - ref).norm() / ref.norm())
+    print(f"[fp8 flash block] vs mx8 emulation rel_l2 {e_emu:.3e}; vs fp32 oracle rel_l2 {e_ref:.3e}")
+    assert e_emu < 2e-2 and e_ref < 5e-2
