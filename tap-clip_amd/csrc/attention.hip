@@ -333,7 +333,7 @@ __global__ __launch_bounds__(512) void attn_flash_kernel(AttnArgs a) {
   // K/V rows of a key block: global -> registers -> LDS.  Without the hi/lo split the registers of block kb + 1 are
   // loaded BEFORE block kb is computed (the workgroup is alone on its CU at this register count, so nothing else
   // would hide that latency) and written to LDS after it.
-  constexpr int N_IT = KEYS * 8 / 512;
+  constexpr int N_IT = (KEYS * 8 + 511) / 512;  // (KEYS * 8 need not be a multiple of 512: guarded below)
   constexpr bool PREFETCH = !SPLIT;
   uint4 kvr[N_IT], vvr[N_IT], kvlr[SPLIT ? N_IT : 1], vvlr[SPLIT ? N_IT : 1];
   auto fetch_block = [&](int kb) {
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(512) void attn_flash_kernel(AttnArgs a) {
         kvlr[it] = kvr[it];
         vvlr[it] = kvr[it];
       }
-      if (key < T) {
+      if (key < T && kk < KEYS) {
         const int64_t base = (row0 + key) * ld + kc * 8;
         kvr[it] = *reinterpret_cast<const uint4*>(a.qkv_hi + base + kcol);
         vvr[it] = *reinterpret_cast<const uint4*>(a.qkv_hi + base + vcol);
@@ -368,6 +368,7 @@ __global__ __launch_bounds__(512) void attn_flash_kernel(AttnArgs a) {
     for (int it = 0; it < N_IT; ++it) {
       const int c = tid + 512 * it;
       const int kk = c >> 3, kc = c & 7;
+      if (kk >= KEYS) continue;
       const int ko = kk * 128 + ((kc ^ (kk & 7)) << 4);
       const int vs = (kk >> 1) & 3;  // quad swizzle of the V image, as in attn_kernel
       const int vo = kk * 128 + ((kc >> 1) << 5) + (((kc & 1) ^ (vs >> 1)) << 4);
@@ -483,9 +484,8 @@ __global__ __launch_bounds__(512) void attn_flash_kernel(AttnArgs a) {
   }
 }
 
-template <bool SPLIT, int QT>
+template <bool SPLIT, int QT, int KB>
 hipError_t launch_flash_q(const AttnArgs& a, hipStream_t s) {
-  constexpr int KB = 8;
   static bool attr_set = false;
   const int smem_bytes = KB * 16 * 128 * (SPLIT ? 4 : 2);
   if (!attr_set) {
@@ -503,16 +503,30 @@ hipError_t launch_flash_q(const AttnArgs& a, hipStream_t s) {
 
 template <bool SPLIT>
 hipError_t launch_flash(const AttnArgs& a, hipStream_t s) {
-  // query tiles per wave: as few K/V re-stagings (query chunks of 8 * QT tiles) as the registers allow
-  static const int forced = [] {
+  // Query tiles per wave (QT) and key tiles per block (KB) decide the register count, and that decides whether one
+  // or two workgroups share a CU.  bf16 / fp16: QT = 2, KB = 4 -> 114 VGPRs, two workgroups per CU (4 waves per
+  // SIMD): 161 us at n = 64, T = 577, against 209 us for QT = 3, KB = 8 (224 VGPRs, one workgroup per CU, fewer
+  // K/V re-stagings).  bf16x3 keeps QT = 2 / 3 at KB = 8 (its hi + lo fragments do not fit the smaller budget).
+  // TAPCLIP_FLASH_QT / TAPCLIP_FLASH_KB pin the choice (tools/gemm_bench).
+  static const int forced_qt = [] {
     const char* e = getenv("TAPCLIP_FLASH_QT");
     return e ? atoi(e) : 0;
   }();
+  static const int forced_kb = [] {
+    const char* e = getenv("TAPCLIP_FLASH_KB");
+    return e ? atoi(e) : 0;
+  }();
   const int n_qt = (a.T + 15) / 16;
-  // (5 tiles per wave would cover 577 tokens in one chunk but spills: 239 us vs 365 us at n = 64, T = 577)
-  const int qt = forced ? forced : (n_qt <= 16 ? 2 : 3);
-  if (qt == 2) return launch_flash_q<SPLIT, 2>(a, s);
-  return launch_flash_q<SPLIT, 3>(a, s);
+  if (SPLIT) {
+    const int qt = forced_qt ? forced_qt : (n_qt <= 16 ? 2 : 3);
+    if (qt == 2) return launch_flash_q<SPLIT, 2, 8>(a, s);
+    return launch_flash_q<SPLIT, 3, 8>(a, s);
+  }
+  const int qt = forced_qt ? forced_qt : 2;
+  const int kb = forced_kb ? forced_kb : 4;
+  if (qt == 3) return kb == 4 ? launch_flash_q<SPLIT, 3, 4>(a, s) : kb == 6 ? launch_flash_q<SPLIT, 3, 6>(a, s) : launch_flash_q<SPLIT, 3, 8>(a, s);
+  if (qt == 1) return kb == 4 ? launch_flash_q<SPLIT, 1, 4>(a, s) : kb == 6 ? launch_flash_q<SPLIT, 1, 6>(a, s) : launch_flash_q<SPLIT, 1, 8>(a, s);
+  return kb == 4 ? launch_flash_q<SPLIT, 2, 4>(a, s) : kb == 6 ? launch_flash_q<SPLIT, 2, 6>(a, s) : launch_flash_q<SPLIT, 2, 8>(a, s);
 }
 
 template <int NKT, bool SPLIT>
