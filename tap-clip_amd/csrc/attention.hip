@@ -573,7 +573,8 @@ __global__ void head_mean_kernel(const float* __restrict__ probs, int H, int64_t
 
 hipError_t launch_attention(const AttnArgs& a, bool split, hipStream_t s) {
   if (a.T <= 0 || a.D != a.H * 64 || a.n_seq <= 0) return hipErrorInvalidValue;
-  if (a.T > 256) {  // whole-head-in-LDS kernel holds at most 256 keys: flash-style kernel (no probability write-back)
+  static const bool force_flash = getenv("TAPCLIP_ATTN_FORCE_FLASH") != nullptr;  // tools/gemm_bench: compare the two kernels
+  if (a.T > 256 || (force_flash && a.probs == nullptr)) {  // whole-head-in-LDS kernel holds at most 256 keys: flash-style kernel (no probability write-back)
     if (a.probs != nullptr) return hipErrorInvalidValue;
     return split ? launch_flash<true>(a, s) : launch_flash<false>(a, s);
   }
