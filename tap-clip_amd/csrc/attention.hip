@@ -89,7 +89,7 @@ __device__ __forceinline__ void store_o_mx8(const AttnArgs& a, const f32x4_t (&o
 }
 
 template <int NKT, bool SPLIT>
-__global__ __launch_bounds__(512) void attn_kernel(AttnArgs a) {
+__global__ __launch_bounds__(512, (NKT % 2) ? 6 : 1) void attn_kernel(AttnArgs a) {
   constexpr int KEYS = NKT * 16;
   constexpr int TILE = KEYS * 128;  // bytes of one [KEYS][64] bf16 image
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -111,17 +111,21 @@ __global__ __launch_bounds__(512) void attn_kernel(AttnArgs a) {
   // overlaps it.  B[k = d = 32*s + 8*g + j][col = q]; queries past T are clamped (never stored).
   constexpr int QT_MAX = (NKT + 7) / 8;  // 16-query tiles per wave (8 waves)
   const int n_qt = (T + 15) >> 4;
-  bf16x8_t qh[QT_MAX][2], ql[SPLIT ? QT_MAX : 1][2];
-#pragma unroll
-  for (int t = 0; t < QT_MAX; ++t) {
+  constexpr bool LEAN = (NKT % 2) != 0;  // 80-VGPR build (three workgroups per CU): Q fragments loaded per tile
+  bf16x8_t qh[LEAN ? 1 : QT_MAX][2], ql[SPLIT ? QT_MAX : 1][2];
+  auto load_q = [&](int t, int slot) {
     int qc = (wave + 8 * t) * 16 + r;
     if (qc >= T) qc = T - 1;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int64_t off = (row0 + qc) * ld + qcol + 32 * s + 8 * g;
-      qh[t][s] = *reinterpret_cast<const bf16x8_t*>(a.qkv_hi + off);
-      if (SPLIT) ql[t][s] = *reinterpret_cast<const bf16x8_t*>(a.qkv_lo + off);
+      qh[slot][s] = *reinterpret_cast<const bf16x8_t*>(a.qkv_hi + off);
+      if (SPLIT) ql[slot][s] = *reinterpret_cast<const bf16x8_t*>(a.qkv_lo + off);
     }
+  };
+  if (!LEAN) {
+#pragma unroll
+    for (int t = 0; t < QT_MAX; ++t) load_q(t, t);
   }
 
   // ---- stage K (swizzled) and V (plain) of this head into LDS; rows >= T are zero.  The trip count
@@ -174,6 +178,8 @@ __global__ __launch_bounds__(512) void attn_kernel(AttnArgs a) {
     const int qt = wave + 8 * t;
     if (qt >= n_qt) break;       // wave-uniform
     const int qi = qt * 16 + r;  // this lane's query (column of S^T)
+    if (LEAN) load_q(t, 0);
+    const int qs = LEAN ? 0 : t;
 
     // ---- S^T = K . Q^T
     f32x4_t sc[NKT];
@@ -185,10 +191,10 @@ __global__ __launch_bounds__(512) void attn_kernel(AttnArgs a) {
       for (int s = 0; s < 2; ++s) {
         const int off = key * 128 + (((4 * s + g) ^ (key & 7)) << 4);
         const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Kh + off);
-        sc[kt] = TAPCLIP_MFMA_16x16x32(kf, qh[t][s], sc[kt]);
+        sc[kt] = TAPCLIP_MFMA_16x16x32(kf, qh[qs][s], sc[kt]);
         if (SPLIT) {
           const bf16x8_t kfl = *reinterpret_cast<const bf16x8_t*>(Kl + off);
-          sc[kt] = TAPCLIP_MFMA_16x16x32(kfl, qh[t][s], sc[kt]);
+          sc[kt] = TAPCLIP_MFMA_16x16x32(kfl, qh[qs][s], sc[kt]);
           sc[kt] = TAPCLIP_MFMA_16x16x32(kf, ql[t][s], sc[kt]);
         }
       }
@@ -243,13 +249,15 @@ __global__ __launch_bounds__(512) void attn_kernel(AttnArgs a) {
     // transposed-read lane address: in-group index i = 4*qq + pp supplies row qq, columns 4*pp..4*pp+3
     const int qq = r >> 2, pp = r & 3;
 #pragma unroll
-    for (int s2 = 0; s2 < NKT / 2; ++s2) {
+    for (int s2 = 0; s2 < (NKT + 1) / 2; ++s2) {
+      // (odd NKT: the last step has one key tile; its upper half multiplies zeros into a re-read of the same keys)
+      const bool half_step = (NKT % 2) && s2 == NKT / 2;
       bf16x8_t ph, pl;
       {
         bf16_t h[8], l[8];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
-          const float p = sc[2 * s2 + (jj >> 2)][jj & 3];
+          const float p = (half_step && jj >= 4) ? 0.f : sc[(2 * s2 + (jj >> 2)) < NKT ? 2 * s2 + (jj >> 2) : NKT - 1][jj & 3];
           if (SPLIT) split_bf(p, h[jj], l[jj]);
           else h[jj] = f2bf(p);
         }
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(512) void attn_kernel(AttnArgs a) {
         }
       }
       const int key0 = 16 * (2 * s2) + 4 * g + qq;
-      const int key1 = 16 * (2 * s2 + 1) + 4 * g + qq;
+      const int key1 = half_step ? key0 : 16 * (2 * s2 + 1) + 4 * g + qq;
       const int sw = (key0 >> 1) & 3;  // == (key1 >> 1) & 3: the keys differ by 16
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
@@ -545,6 +553,10 @@ hipError_t launch_t(const AttnArgs& a, hipStream_t s) {
 
 template <bool SPLIT>
 hipError_t dispatch(const AttnArgs& a, hipStream_t s) {
+  // 197 tokens (ViT-B/16): 13 key tiles make the K and V images 2 x 26 KiB, so three workgroups fit a CU's LDS, and
+  // that instantiation is compiled for 6 waves per SIMD (80 VGPRs)
+  static const bool no13 = getenv("TAPCLIP_ATTN_NO13") != nullptr;
+  if (!SPLIT && !no13 && a.T > 192 && a.T <= 208) return launch_t<13, SPLIT>(a, s);
   const int nkt = ((a.T + 31) / 32) * 2;  // even number of 16-key tiles
   switch (nkt) {
     case 2: return launch_t<2, SPLIT>(a, s);

@@ -22,8 +22,10 @@ HOT = [
     # 256-wide tiles and is therefore always launched 128-wide: gemm256.hip launch_e)
     ("gemm256.hip", r"gemm256_kernelILi[0-4]ELb0ELi(256|128)ELi4E|gemm256_kernelILi5ELb0ELi128ELi4E"),
     ("gemm_mx8.hip", r"gemm_mx8_kernelILi[046]E"),
-    ("attention.hip", r"attn_kernelILi(6|14)ELb0E|attn_flash_kernelILi8ELi[23]ELb0E"),
+    ("attention.hip", r"attn_kernelILi(6|14)ELb0E|attn_flash_kernelILi(4|8)ELi[23]ELb0E"),
 ]
+# the 13-key-tile attention kernel is compiled for 6 waves per SIMD (three workgroups per CU) and parks 3 dwords
+SMALL_SPILL = {"attention.hip": (r"attn_kernelILi13ELb0E", 16)}
 
 
 def _usage(src):
@@ -52,3 +54,7 @@ def test_hot_kernels_use_no_scratch():
         assert hot, f"no kernel of {src} matched {pat}: {sorted(usage)[:5]}"
         spilled = {k: v for k, v in hot.items() if v != 0}
         assert not spilled, f"{src}: scratch in hot kernels {spilled}"
+        if src in SMALL_SPILL:
+            pat2, limit = SMALL_SPILL[src]
+            lean = {k: v for k, v in usage.items() if re.search(pat2, k)}
+            assert lean and all(v <= limit for v in lean.values()), f"{src}: {lean}"
