@@ -73,7 +73,7 @@ class _LogitsFn(torch.autograd.Function):
 class FullModel(nn.Module):
     def __init__(self, class_names, clip_wrapper, prompt_len=5, attr_lambda=1.0, stab_lambda=0.1,
                  adjustor_method='scale', class_specific=False, *, collapse_text: bool = True,
-                 gather_images: bool = False, overlap_towers: bool = True):
+                 gather_images: bool = False, overlap_towers: bool = True, cache_text_features: bool = False):
         super().__init__()
         self.clip = clip_wrapper
         self.class_names = class_names
@@ -93,6 +93,11 @@ class FullModel(nn.Module):
         # on 256 CUs) instead of after them.
         self.overlap_towers = overlap_towers
         self._side_stream = None
+        # Evaluation helper (off by default; bench.py never uses it): the text features do not depend on the images,
+        # so a no-grad forward may re-use them while no prompt parameter, CLIP weight or adjustor setting has changed.
+        # The reference recomputes them for every batch (model_wrapper.py:47-75).
+        self.cache_text_features = cache_text_features
+        self._text_cache = None
         # a checkpoint that carries other `clip.model.*` weights re-packs the towers (clip_wrapper.py here);
         # the frozen class-token embeddings derived from them are then re-computed as well
         self._clip_version = getattr(clip_wrapper, "weights_version", 0)
@@ -129,8 +134,23 @@ class FullModel(nn.Module):
         return feat
 
     # ---- text side -----------------------------------------------------------------------------
+    def _text_cache_key(self):
+        params = list(self.prompt_learner.parameters()) + list(self.prompt_adjustor.parameters())
+        return (tuple((p.data_ptr(), p._version) for p in params), getattr(self.clip, "weights_version", 0),
+                self.prompt_adjustor.method, self.clip.attn_semantics, len(self.prompt_learner.context_bank))
+
     def text_features(self) -> torch.Tensor:
         """L2-normalised text features [n_cls, E] (reference model_wrapper.py:47-75, collapsed)."""
+        if self.cache_text_features and not torch.is_grad_enabled():
+            key = self._text_cache_key()
+            if self._text_cache is not None and self._text_cache[0] == key:
+                return self._text_cache[1]
+            feats = self._text_features_uncached()
+            self._text_cache = (key, feats)
+            return feats
+        return self._text_features_uncached()
+
+    def _text_features_uncached(self) -> torch.Tensor:
         pl, clip = self.prompt_learner, self.clip
         P = pl.prompt_len
         ctx, tok = pl.stacked_context().detach(), pl.stacked_tokens()

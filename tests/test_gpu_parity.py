@@ -600,3 +600,31 @@ def test_fp16_text_tower_stays_bf16(eng):
     cfg = configs.get_config("tiny")
     sd = synth.make_state_dict(cfg, seed=2)
     assert eng.TextTower(cfg, sd, DEV, "fp16").precision == "bf16"
+
+
+def test_text_feature_cache_is_opt_in_and_invalidates():
+    """`FullModel(cache_text_features=True)`: identical logits, and the cache follows parameter updates."""
+    from tap_clip_amd.models import CLIPWrapper, FullModel
+    cfg = configs.get_config("tiny")
+    sd = synth.make_state_dict(cfg, seed=2)
+    torch.manual_seed(5)
+    clip = CLIPWrapper("tiny", None, DEV, state_dict=sd)
+    model = FullModel(["Mug", "Pen", "Bag"], clip, prompt_len=5, class_specific=True, cache_text_features=True).eval()
+    assert FullModel(["Mug"], clip, prompt_len=5).cache_text_features is False
+    images = synth.make_images(4, cfg, 3).to(DEV)
+    with torch.no_grad():
+        a = model(images)["logits"]
+        assert model._text_cache is not None
+        b = model(images)["logits"]      # served from the cache
+        assert torch.equal(a, b)
+        model.cache_text_features = False
+        assert torch.equal(model(images)["logits"], a)
+        model.cache_text_features = True
+        # like an optimiser step: bumps the version counter.  (Not a constant shift or a rescaling of the tokens: the
+        # pre-LN blocks are invariant to both as far as the pooled last token is concerned.)
+        ctx_p = model.prompt_learner.context_bank["Mug"]
+        ctx_p.add_(synth.normal(list(ctx_p.shape), 77, "cache.noise").to(DEV))
+        c = model(images)["logits"]
+        assert not torch.equal(c, a)
+        model.cache_text_features = False
+        assert torch.equal(model(images)["logits"], c)
