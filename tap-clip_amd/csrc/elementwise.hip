@@ -124,8 +124,11 @@ __global__ void scale_copy_kernel(const float* __restrict__ src, int64_t n, int6
 // models/clip_wrapper.py:47 + models/model_wrapper.py:41).  text: token -1, text_projection, norm
 // (reference models/model_wrapper.py:73-75); encode_text: EOT row, ln_final (clip_wrapper.py:49-51).
 // One workgroup per output row; fp32 FMA throughout (0.8 MFLOP per row).
+// The projection's K range is split over KSPL groups of 256 threads (each thread's loop is a chain of L2 round trips:
+// 96 of them at K = 768 made this a 60-us kernel for 0.2 GFLOP); the partial sums meet in LDS.
+constexpr int POOL_KSPL = 4;
 template <int NE>  // outputs per thread: E <= 256 * NE
-__global__ __launch_bounds__(256) void pool_project_kernel(const float* __restrict__ src,
+__global__ __launch_bounds__(256 * POOL_KSPL) void pool_project_kernel(const float* __restrict__ src,
                                                            const bf16_t* __restrict__ dhi,
                                                            const bf16_t* __restrict__ dlo, int tokens, int K,
                                                            const int64_t* __restrict__ index, int fixed_token,
@@ -133,42 +136,52 @@ __global__ __launch_bounds__(256) void pool_project_kernel(const float* __restri
                                                            const float* __restrict__ ln_b,
                                                            const float* __restrict__ proj, int E, int normalize,
                                                            float* out) {
-  extern __shared__ float sh[];  // K floats (row) + 8 floats (reductions)
+  extern __shared__ float sh[];  // K floats (row) + 8 floats (reductions) + POOL_KSPL x E partial sums
   float* row = sh;
   float* red = sh + K;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* part = red + 8;
+  const int tid_all = threadIdx.x, kq = tid_all >> 8;  // K quarter of this thread
+  const int tid = tid_all & 255, lane = tid & 63, wave = tid >> 6;
+  const bool lead = kq == 0;  // the first 256 threads do the row staging, the LayerNorm and the final sum
   const int64_t n = blockIdx.x;
   int tok = fixed_token;
   if (index != nullptr) tok = (int)index[n];
   if (tok < 0) tok += tokens;
   const int64_t roff = (n * tokens + tok) * (int64_t)K;
   const float* xr = src + roff;
-  for (int c = tid; c < K; c += 256) {
-    float t = xr[c];
-    if (dhi != nullptr) t += bf2f(dhi[roff + c]);
-    if (dlo != nullptr) t += bf2f(dlo[roff + c]);
-    row[c] = t;
+  if (lead) {
+    for (int c = tid; c < K; c += 256) {
+      float t = xr[c];
+      if (dhi != nullptr) t += bf2f(dhi[roff + c]);
+      if (dlo != nullptr) t += bf2f(dlo[roff + c]);
+      row[c] = t;
+    }
   }
   __syncthreads();
-  if (ln_g != nullptr) {
+  if (ln_g != nullptr) {  // (workgroup-uniform; the non-lead threads only keep the barriers company)
     float s = 0.f;
-    for (int c = tid; c < K; c += 256) s += row[c];
-    s = wave_sum(s);
-    if (lane == 0) red[wave] = s;
+    if (lead) {
+      for (int c = tid; c < K; c += 256) s += row[c];
+      s = wave_sum(s);
+      if (lane == 0) red[wave] = s;
+    }
     __syncthreads();
     const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)K;
     __syncthreads();
-    float ss = 0.f;
-    for (int c = tid; c < K; c += 256) {
-      const float t = row[c] - mean;
-      ss += t * t;
+    if (lead) {
+      float ss = 0.f;
+      for (int c = tid; c < K; c += 256) {
+        const float t = row[c] - mean;
+        ss += t * t;
+      }
+      ss = wave_sum(ss);
+      if (lane == 0) red[wave] = ss;
     }
-    ss = wave_sum(ss);
-    if (lane == 0) red[wave] = ss;
     __syncthreads();
     const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + 1e-5f);
     __syncthreads();
-    for (int c = tid; c < K; c += 256) row[c] = (row[c] - mean) * rstd * ln_g[c] + ln_b[c];
+    if (lead)
+      for (int c = tid; c < K; c += 256) row[c] = (row[c] - mean) * rstd * ln_g[c] + ln_b[c];
     __syncthreads();
   }
   // projection: 8 k-steps of loads are issued together (unconditional, clamped column index) so the
@@ -180,7 +193,9 @@ __global__ __launch_bounds__(256) void pool_project_kernel(const float* __restri
     acc[j] = 0.f;
     ec[j] = tid + 256 * j < E ? tid + 256 * j : E - 1;
   }
-  for (int k0 = 0; k0 < K; k0 += 8) {
+  const int kper = (K / 8 + POOL_KSPL - 1) / POOL_KSPL * 8;  // this group's K range (multiples of 8; K % 8 == 0)
+  const int k_lo = kq * kper, k_hi = k_lo + kper < K ? k_lo + kper : K;
+  for (int k0 = k_lo; k0 < k_hi; k0 += 8) {
     float pv[8][NE];
 #pragma unroll
     for (int u = 0; u < 8; ++u)
@@ -193,21 +208,40 @@ __global__ __launch_bounds__(256) void pool_project_kernel(const float* __restri
       for (int j = 0; j < NE; ++j) acc[j] = fmaf(xv, pv[u][j], acc[j]);
     }
   }
+  // partial sums of the K groups -> LDS, summed in group order (a fixed order: run-to-run identical)
+#pragma unroll
+  for (int j = 0; j < NE; ++j)
+    if (tid + 256 * j < E) part[kq * E + tid + 256 * j] = acc[j];
+  __syncthreads();
+  if (lead) {
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const int e = tid + 256 * j < E ? tid + 256 * j : E - 1;
+      float v = part[e];
+#pragma unroll
+      for (int g2 = 1; g2 < POOL_KSPL; ++g2) v += part[g2 * E + e];
+      acc[j] = v;
+    }
+  }
   float scale = 1.f;
   if (normalize) {
-    float ss = 0.f;
+    if (lead) {
+      float ss = 0.f;
 #pragma unroll
-    for (int j = 0; j < NE; ++j)
-      if (tid + 256 * j < E) ss += acc[j] * acc[j];
-    ss = wave_sum(ss);
-    if (lane == 0) red[4 + wave] = ss;
+      for (int j = 0; j < NE; ++j)
+        if (tid + 256 * j < E) ss += acc[j] * acc[j];
+      ss = wave_sum(ss);
+      if (lane == 0) red[4 + wave] = ss;
+    }
     __syncthreads();
     scale = 1.0f / sqrtf(red[4] + red[5] + red[6] + red[7]);
   }
+  if (lead) {
 #pragma unroll
-  for (int j = 0; j < NE; ++j) {
-    const int e = tid + 256 * j;
-    if (e < E) out[n * E + e] = acc[j] * scale;
+    for (int j = 0; j < NE; ++j) {
+      const int e = tid + 256 * j;
+      if (e < E) out[n * E + e] = acc[j] * scale;
+    }
   }
 }
 
@@ -269,26 +303,33 @@ __global__ void build_prompts_kernel(const float* __restrict__ ctx, const float*
 }
 
 // ---- K13: logits[b, c] = scale * <img[b], txt[c]> (reference models/model_wrapper.py:79,83).
-// One thread per logit, float4 loads (both operands are a few hundred KB: L1/L2 resident).
+// Sixteen lanes per logit (float4 loads, 256 contiguous bytes per group and step), xor-shuffle reduction: at
+// 256 x 65 logits one thread per logit was a 24-us chain of 128 dependent FMAs on 6 % of the chip.
 __global__ __launch_bounds__(256) void logits_kernel(const float* __restrict__ img, const float* __restrict__ txt,
                                                      float scale, int B, int C, int E, float* out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)B * C) return;
-  const int b = (int)(i / C), c = (int)(i - (int64_t)b * C);
-  const float* ir = img + (int64_t)b * E;
-  const float* tr = txt + (int64_t)c * E;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = t >> 4;  // logit index; the 16 lanes of a group stay together (inactive groups still shuffle)
+  const int sub = (int)(t & 15);
+  const bool live = i < (int64_t)B * C;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int e = 0;
-  if (E % 4 == 0) {
-#pragma unroll 4
-    for (; e < E; e += 4) {
-      const float4 a = *reinterpret_cast<const float4*>(ir + e);
-      const float4 w = *reinterpret_cast<const float4*>(tr + e);
-      s0 = fmaf(a.x, w.x, s0); s1 = fmaf(a.y, w.y, s1); s2 = fmaf(a.z, w.z, s2); s3 = fmaf(a.w, w.w, s3);
+  if (live) {
+    const int b = (int)(i / C), c = (int)(i - (int64_t)b * C);
+    const float* ir = img + (int64_t)b * E;
+    const float* tr = txt + (int64_t)c * E;
+    if (E % 4 == 0) {
+      for (int e = 4 * sub; e < E; e += 64) {
+        const float4 a = *reinterpret_cast<const float4*>(ir + e);
+        const float4 w = *reinterpret_cast<const float4*>(tr + e);
+        s0 = fmaf(a.x, w.x, s0); s1 = fmaf(a.y, w.y, s1); s2 = fmaf(a.z, w.z, s2); s3 = fmaf(a.w, w.w, s3);
+      }
+    } else {
+      for (int e = sub; e < E; e += 16) s0 = fmaf(ir[e], tr[e], s0);
     }
   }
-  for (; e < E; ++e) s0 = fmaf(ir[e], tr[e], s0);
-  out[i] = scale * ((s0 + s1) + (s2 + s3));
+  float v = (s0 + s1) + (s2 + s3);
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if (live && sub == 0) out[i] = scale * v;
 }
 
 __global__ void add_delta_kernel(float* __restrict__ x, const bf16_t* __restrict__ dhi, const bf16_t* __restrict__ dlo,
@@ -352,8 +393,8 @@ hipError_t launch_pool_project(const float* src, const bf16_t* dhi, const bf16_t
                                const float* ln_b, const float* proj, int32_t E, int32_t normalize, float* out,
                                hipStream_t s) {
   if (E > 1024 || K > 8192 || K % 8 != 0) return hipErrorInvalidValue;
-  const dim3 grid((unsigned)n), block(256);
-  const size_t sh = (K + 8) * sizeof(float);
+  const dim3 grid((unsigned)n), block(256 * POOL_KSPL);
+  const size_t sh = (K + 8 + (size_t)POOL_KSPL * E) * sizeof(float);
   switch ((E + 255) / 256) {
     case 1: hipLaunchKernelGGL((pool_project_kernel<1>), grid, block, sh, s, src, dhi, dlo, tokens, K, index, fixed_token, ln_g, ln_b, proj, E, normalize, out); break;
     case 2: hipLaunchKernelGGL((pool_project_kernel<2>), grid, block, sh, s, src, dhi, dlo, tokens, K, index, fixed_token, ln_g, ln_b, proj, E, normalize, out); break;
@@ -396,7 +437,7 @@ hipError_t launch_build_prompts(const float* ctx, const float* tok, const float*
 
 hipError_t launch_logits(const float* img, const float* txt, float scale, int32_t B, int32_t C, int32_t E, float* out,
                          hipStream_t s) {
-  hipLaunchKernelGGL(logits_kernel, dim3(blocks_for((int64_t)B * C, 256)), dim3(256), 0, s, img, txt, scale, B, C, E, out);
+  hipLaunchKernelGGL(logits_kernel, dim3(blocks_for((int64_t)B * C * 16, 256)), dim3(256), 0, s, img, txt, scale, B, C, E, out);
   return hipGetLastError();
 }
 
