@@ -23,6 +23,8 @@ Extra objects on the same line:
                 the split-bf16 parity mode.
   full_forward  FullModel.forward at configs[2] (image + text towers, 65 classes, 16 context tokens,
                 attention-map write-back on): logits/s, measured after the timed region.
+  input_side    CLIP's eval transform (bicubic resize, crop, normalise) of uint8 photos on the GPU
+                (tapclip_preprocess_u8), with the reference's Pillow CPU path on one core beside it.
 """
 import argparse
 import json
@@ -71,6 +73,7 @@ def main():
                     help="bf16 = the benchmarked fast path; bf16x3 = the split-bf16 parity mode (3 MFMA products)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-forward", action="store_true")
+    ap.add_argument("--no-input-side", action="store_true", help="skip the GPU preprocess measurement")
     ap.add_argument("--no-precisions", action="store_true", help="skip the bf16 / fp16 / fp8 comparison table")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
@@ -271,6 +274,75 @@ def main():
         result["train_step"] = {"workload": "prompt-tuning step: FullModel forward + CE + backward to 65 x [16,512] context tokens + AdamW, "
                                             "batch %d (image tower forward only: frozen)" % args.batch,
                                 "ms_per_step": round(1e3 * dt_t, 3), "images_per_sec": round(args.batch / dt_t, 1)}
+    if rank == 0 and world == 1 and not args.no_input_side:
+        # Input side: CLIP's eval transform of decoded uint8 photos on the GPU, bit-identical to the
+        # Pillow + torchvision transform the reference runs per sample in its loader workers (dataset.py:29-35).
+        g = torch.Generator(device="cpu").manual_seed(5)
+        photo_hw = (375, 500)
+        photos = [torch.randint(0, 256, (*photo_hw, 3), dtype=torch.uint8, generator=g).to(dev) for _ in range(args.batch)]
+        size = cfg.image_size
+        for _ in range(2):
+            pre = engine.preprocess_u8(photos, size=size, device=dev)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_it = max(3, args.steps // 4)
+        t1 = time.perf_counter()
+        for _ in range(n_it):
+            pre = engine.preprocess_u8(photos, size=size, device=dev)
+        torch.cuda.synchronize(dev)
+        dt_host = (time.perf_counter() - t1) / n_it
+        # the two kernels alone: the C-ABI call on prepared descriptors (the python wrapper above spends ~1.5 us per
+        # image building them)
+        import ctypes as C
+        from tap_clip_amd import _lib
+
+        desc = torch.tensor([(p.data_ptr() - photos[0].data_ptr(), photo_hw[0], photo_hw[1], i * photo_hw[0] * size * 3)
+                             for i, p in enumerate(photos)], dtype=torch.int64).to(dev)
+        ws = torch.empty(args.batch * photo_hw[0] * size * 3, dtype=torch.uint8, device=dev)
+        ms6 = (C.c_float * 6)(*engine.CLIP_MEAN, *engine.CLIP_STD)
+        lib, st = _lib.load(), torch.cuda.current_stream(dev).cuda_stream
+        call = lambda: _lib.check(lib.tapclip_preprocess_u8(photos[0].data_ptr(), desc.data_ptr(), args.batch, size, ms6,
+                                                            ws.data_ptr(), pre.data_ptr(), st))
+        call()
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(n_it):
+            call()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        dt_dev = e0.elapsed_time(e1) * 1e-3 / n_it
+        with torch.no_grad():
+            vision.encode_image(pre, normalize=True)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(n_it):
+                vision.encode_image(engine.preprocess_u8(photos, size=size, device=dev), normalize=True)
+            torch.cuda.synchronize(dev)
+            dt_both = (time.perf_counter() - t1) / n_it
+        # algorithmic bytes: read the photo once, write + read the horizontally resampled rows, write fp32 CHW
+        pp_bytes = args.batch * (photo_hw[0] * photo_hw[1] * 3 + 2 * photo_hw[0] * size * 3 + size * size * 3 * 4)
+        entry = {"workload": f"{args.batch} uint8 RGB photos {photo_hw[0]}x{photo_hw[1]} resident in HBM -> [{args.batch},3,{size},{size}] fp32: "
+                             "Resize(bicubic) + CenterCrop + ToTensor + Normalize (tapclip_preprocess_u8; images_per_sec through the python wrapper)",
+                 "images_per_sec": round(args.batch / dt_host, 1), "ms_per_batch": round(1e3 * dt_host, 3),
+                 "ms_per_batch_kernels": round(1e3 * dt_dev, 3),
+                 "hbm": {"achieved_GBps": round(pp_bytes / dt_dev / 1e9, 1), "peak_GBps": HBM_PEAK_GBS, "bytes_per_batch": pp_bytes},
+                 "preprocess_plus_encode_images_per_sec": round(args.batch / dt_both, 1)}
+        try:  # the reference's own CPU path for the same photos, one core (Pillow is what its transform calls)
+            from PIL import Image
+            from tap_clip_amd.models.clip_wrapper import _make_preprocess
+
+            cpu_pre = _make_preprocess(size)
+            pil = [Image.fromarray(p.cpu().numpy()) for p in photos[:16]]
+            torch.set_num_threads(1)
+            t1 = time.perf_counter()
+            outs = [cpu_pre(im) for im in pil]
+            dt_cpu = (time.perf_counter() - t1) / len(pil)
+            entry["cpu_pillow_images_per_sec_one_core"] = round(1.0 / dt_cpu, 1)
+            entry["bit_identical_to_cpu_path"] = bool(torch.equal(torch.stack(outs), pre[:16].cpu()))
+        except ImportError:
+            pass
+        result["input_side"] = entry
+        del photos, pre
     if rank == 0 and world == 1 and not args.no_precisions:
         # The other precisions of the image tower on the same step (fewer steps), each with its live embedding error
         # against the split-bf16 parity mode (itself 4e-6 from the fp32 reference, tests/test_gpu_parity.py).

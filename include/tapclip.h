@@ -187,6 +187,18 @@ int tapclip_build_prompts(const float* ctx, const float* tok, const float* attri
 int tapclip_logits(const float* img, const float* txt, float scale, int32_t B, int32_t C, int32_t E,
                    float* out, tapclip_stream_t stream);
 
+/* ---- the eval transform of `clip.get_preprocess()` (reference models/clip_wrapper.py:56-59 returns open_clip's
+ * image_transform(is_train=False); dataset.py:29-35 applies it per sample): Resize(size, BICUBIC) ->
+ * CenterCrop(size) -> ToTensor -> Normalize(mean, std), for B decoded uint8 RGB images of any sizes.
+ * The resize reproduces Pillow's 8-bit bicubic resampling bit for bit (horizontal pass, then vertical, each
+ * rounded to uint8), with torchvision's size rules (shorter side -> size, longer side int(size * long / short);
+ * crop origin int(round((n - size) / 2.0))).
+ * pixels: device, [h, w, 3] uint8 images.  desc: device [B][4] int64 = {byte offset of the image from `pixels`
+ * (any sign: images in separate allocations are addressed by their distance to `pixels`), height, width, byte
+ * offset of its scratch in workspace}; image i needs height_i * size * 3 scratch bytes.  mean_std: HOST, mean[3] then std[3].  out: device [B, 3, size, size] fp32. */
+int tapclip_preprocess_u8(const uint8_t* pixels, const int64_t* desc, int32_t B, int32_t size,
+                          const float* mean_std, void* workspace, float* out, tapclip_stream_t stream);
+
 /* ---- unit entry points for the per-kernel parity tests and roofline micro-benches
  * (SURVEY.md section 2.1 K2 and K3/K5/K6/K7).  Row-major fp32 in/out. -------- */
 /* y = LayerNorm(x) * gamma + beta, eps 1e-5; rows x d. */

@@ -43,6 +43,7 @@ SYMBOLS = [
     ("tapclip_attribution", _i32, [_p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     ("tapclip_build_prompts", _i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     ("tapclip_logits", _i32, [_p, _p, _f32, _i32, _i32, _i32, _p, _p]),
+    ("tapclip_preprocess_u8", _i32, [_p, _p, _i32, _i32, _p, _p, _p, _p]),
     ("tapclip_layernorm_f32", _i32, [_p, _p, _p, _i64, _i32, _p, _p]),
     ("tapclip_gemm_scratch_bytes", _sz, [_i64, _i32, _i32]),
     ("tapclip_gemm_f32", _i32, [_p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _sz, _p]),

@@ -91,6 +91,11 @@ hipError_t launch_layernorm_mx8(int add, float* x, bf16_t* x16, const bf16_t* d1
                                 const float* beta, int64_t rows, int32_t d, uint8_t* out_q, uint8_t* out_sc, int64_t rows_pad, hipStream_t s);
 // out[b, :] = x16[b * tokens, :] + delta[b * tokens, :]  (the CLS rows of a 16-bit residual stream, as fp32 [B, D])
 hipError_t launch_gather_cls16(const bf16_t* x16, const bf16_t* delta, int32_t B, int32_t tokens, int32_t D, float* out, hipStream_t s);
+// Resize(size, bicubic) + CenterCrop(size) + ToTensor + Normalize of B packed uint8 RGB images (preprocess.hip).
+// desc [B][4] int64 (device): byte offset of the image in `pixels`, height, width, byte offset of its height*size*3
+// scratch bytes in `ws`.  mean_std: host, mean[3] then std[3].
+hipError_t launch_preprocess_u8(const uint8_t* pixels, const int64_t* desc, int32_t B, int32_t size, const float* mean_std,
+                                uint8_t* ws, float* out, hipStream_t s);
 // x[i] += delta_hi[i] (+ delta_lo[i])
 hipError_t launch_add_delta(float* x, const bf16_t* delta_hi, const bf16_t* delta_lo, int64_t n, hipStream_t s);
 

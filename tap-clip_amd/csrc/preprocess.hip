@@ -1,0 +1,233 @@
+// Input side of the path: the eval transform `clip.get_preprocess()` hands to the dataset
+// (reference models/clip_wrapper.py:56-59 -> open_clip image_transform(is_train=False); dataset.py:29-35 applies it
+// per sample on the CPU): Resize(size, bicubic) -> CenterCrop(size) -> ToTensor -> Normalize, on packed uint8 RGB
+// images already in HBM.
+//
+// The resize is Pillow's 8-bit bicubic (what torchvision's Resize calls for a PIL image), reproduced bit for bit:
+// coefficient rows in fp64 exactly as Resample.c's precompute_coeffs computes them (no FMA contraction in this
+// file), 22-bit fixed point, horizontal pass -> uint8 -> vertical pass -> uint8.  Only the crop window is
+// computed: the horizontal pass writes the `size` columns the crop keeps, for the input rows the vertical pass of
+// the kept rows reads.  Byte / integer work, HBM- and L2-bound by nature: one thread per output sample, coefficient
+// rows of the workgroup's outputs in LDS.
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace tapclip {
+namespace {
+
+constexpr int PRECISION_BITS = 32 - 8 - 2;
+constexpr int VR = 32;    // output rows per workgroup of the vertical pass
+constexpr int KCAP = 129;  // coefficient rows up to this length (scale <= 32) live in LDS; longer ones are re-evaluated per use
+
+struct Axis {
+  double scale, support, ss;
+  int in_size, ksize;
+};
+
+__device__ __forceinline__ Axis make_axis(int in_size, int out_size) {
+  Axis a;
+  a.in_size = in_size;
+  a.scale = (double)in_size / out_size;
+  const double fs = a.scale < 1.0 ? 1.0 : a.scale;
+  a.support = 2.0 * fs;
+  a.ksize = (int)ceil(a.support) * 2 + 1;
+  a.ss = 1.0 / fs;
+  return a;
+}
+
+__device__ __forceinline__ double bicubic(double x) {
+  if (x < 0.0) x = -x;
+  if (x < 1.0) return ((-0.5 + 2.0) * x - (-0.5 + 3.0)) * x * x + 1;
+  if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * -0.5;
+  return 0.0;
+}
+
+struct Taps {
+  double center, ww;
+  int xmin, n;
+};
+
+// bounds and weight sum of output index xx
+__device__ __forceinline__ Taps make_taps(const Axis& a, int xx) {
+  Taps t;
+  t.center = (xx + 0.5) * a.scale;
+  t.xmin = (int)(t.center - a.support + 0.5);
+  if (t.xmin < 0) t.xmin = 0;
+  int xmax = (int)(t.center + a.support + 0.5);
+  if (xmax > a.in_size) xmax = a.in_size;
+  t.n = xmax - t.xmin;
+  t.ww = 0.0;
+  for (int x = 0; x < t.n; ++x) t.ww += bicubic((x + t.xmin - t.center + 0.5) * a.ss);
+  return t;
+}
+
+__device__ __forceinline__ int tap_coeff(const Axis& a, const Taps& t, int x) {
+  double k = bicubic((x + t.xmin - t.center + 0.5) * a.ss);
+  if (t.ww != 0.0) k /= t.ww;
+  return k < 0 ? (int)(-0.5 + k * (1 << PRECISION_BITS)) : (int)(0.5 + k * (1 << PRECISION_BITS));
+}
+
+// the three channel bytes of a pixel in one (unaligned) 32-bit load; reads one byte past the pixel
+__device__ __forceinline__ uint32_t load_px4(const uint8_t* p) {
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
+__device__ __forceinline__ void mac_px(uint32_t v, int k, int& a0, int& a1, int& a2) {
+  a0 += (int)(v & 255u) * k;
+  a1 += (int)((v >> 8) & 255u) * k;
+  a2 += (int)((v >> 16) & 255u) * k;
+}
+__device__ __forceinline__ uint8_t clip8(int v) {
+  v >>= PRECISION_BITS;
+  return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+}
+
+// torchvision Resize(size) / CenterCrop(size) geometry
+struct Geometry {
+  int h, w, nh, nw, top, left;
+};
+__device__ __forceinline__ int half_even(int k) {  // int(round(k / 2.0)), Python rounding
+  const int t = k >> 1;
+  return (k & 1) ? t + (t & 1) : t;
+}
+__device__ __forceinline__ Geometry make_geometry(int h, int w, int size) {
+  Geometry g;
+  g.h = h;
+  g.w = w;
+  if (w <= h) {
+    g.nw = size;
+    g.nh = (int)((double)((int64_t)size * h) / (double)w);
+  } else {
+    g.nh = size;
+    g.nw = (int)((double)((int64_t)size * w) / (double)h);
+  }
+  g.top = half_even(g.nh - size);
+  g.left = half_even(g.nw - size);
+  return g;
+}
+
+// desc[b] = {byte offset of image b in `pixels`, height, width, byte offset of its scratch rows in `ws`}
+__global__ __launch_bounds__(256) void resample_h_kernel(const uint8_t* __restrict__ pixels, const int64_t* __restrict__ desc,
+                                                         int size, uint8_t* __restrict__ ws) {
+  __shared__ int coef[32][KCAP];
+  __shared__ int s_xmin[32], s_n[32];
+  const int b = blockIdx.y;
+  const int h = (int)desc[b * 4 + 1], w = (int)desc[b * 4 + 2];
+  if (h <= 0 || w <= 0) return;
+  const Geometry g = make_geometry(h, w, size);
+  const uint8_t* src = pixels + desc[b * 4 + 0];
+  const uint8_t* src_end = src + (int64_t)h * w * 3;
+  uint8_t* dst = ws + desc[b * 4 + 3];
+  const Axis ax = make_axis(w, g.nw);
+  const Axis ay = make_axis(h, g.nh);
+  // input rows the vertical pass of the kept output rows reads
+  const Taps t_first = make_taps(ay, g.top), t_last = make_taps(ay, g.top + size - 1);
+  const int row_lo = t_first.xmin, row_hi = t_last.xmin + t_last.n;
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);  // column of the crop
+  const bool in_lds = ax.ksize <= KCAP;
+  Taps t = {};
+  if (c < size && (threadIdx.x < 32 || !in_lds)) t = make_taps(ax, c + g.left);
+  if (in_lds) {
+    if (threadIdx.x < 32 && c < size) {
+      for (int x = 0; x < t.n; ++x) coef[threadIdx.x][x] = tap_coeff(ax, t, x);
+      s_xmin[threadIdx.x] = t.xmin;
+      s_n[threadIdx.x] = t.n;
+    }
+    __syncthreads();
+  }
+  if (c >= size) return;
+  const int ci = threadIdx.x & 31;
+  const int xmin = in_lds ? s_xmin[ci] : t.xmin, n = in_lds ? s_n[ci] : t.n;
+  for (int row = row_lo + (int)(threadIdx.x >> 5) + 8 * (int)blockIdx.z; row < row_hi; row += 8 * gridDim.z) {
+    const uint8_t* p = src + ((int64_t)row * w + xmin) * 3;
+    int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+    if (in_lds && n <= 10 && p + 32 <= src_end) {
+      // the usual case (scale <= 2): the sample's <= 30 source bytes as two unaligned 16-byte loads
+      uint32_t v[8];
+      __builtin_memcpy(v, p, 32);
+#pragma unroll
+      for (int x = 0; x < 10; ++x)
+        if (x < n) {
+          const int k = coef[ci][x];
+          a0 += (int)((v[(3 * x) >> 2] >> (8 * ((3 * x) & 3))) & 255u) * k;
+          a1 += (int)((v[(3 * x + 1) >> 2] >> (8 * ((3 * x + 1) & 3))) & 255u) * k;
+          a2 += (int)((v[(3 * x + 2) >> 2] >> (8 * ((3 * x + 2) & 3))) & 255u) * k;
+        }
+    } else {
+#pragma unroll 4
+      for (int x = 0; x < n - 1; ++x) mac_px(load_px4(p + 3 * x), in_lds ? coef[ci][x] : tap_coeff(ax, t, x), a0, a1, a2);
+      if (n > 0) {  // the last tap by bytes: nothing is read past the image
+        const int x = n - 1, k = in_lds ? coef[ci][x] : tap_coeff(ax, t, x);
+        a0 += p[3 * x] * k;
+        a1 += p[3 * x + 1] * k;
+        a2 += p[3 * x + 2] * k;
+      }
+    }
+    uint8_t* o = dst + ((int64_t)row * size + c) * 3;
+    o[0] = clip8(a0);
+    o[1] = clip8(a1);
+    o[2] = clip8(a2);
+  }
+}
+
+__global__ __launch_bounds__(256) void resample_v_normalize_kernel(const int64_t* __restrict__ desc, int size,
+                                                                   const uint8_t* __restrict__ ws, float m0, float m1, float m2,
+                                                                   float s0, float s1, float s2, float* __restrict__ out) {
+  __shared__ int coef[VR][KCAP];
+  __shared__ int s_xmin[VR], s_n[VR];
+  const int b = blockIdx.y;
+  const int h = (int)desc[b * 4 + 1], w = (int)desc[b * 4 + 2];
+  if (h <= 0 || w <= 0) return;
+  const Geometry g = make_geometry(h, w, size);
+  const uint8_t* src = ws + desc[b * 4 + 3];
+  const Axis ay = make_axis(h, g.nh);
+  const bool in_lds = ay.ksize <= KCAP;
+  const int r0 = blockIdx.x * VR;
+  if (in_lds) {
+    if (threadIdx.x < VR && r0 + (int)threadIdx.x < size) {
+      const Taps t = make_taps(ay, r0 + threadIdx.x + g.top);
+      for (int x = 0; x < t.n; ++x) coef[threadIdx.x][x] = tap_coeff(ay, t, x);
+      s_xmin[threadIdx.x] = t.xmin;
+      s_n[threadIdx.x] = t.n;
+    }
+    __syncthreads();
+  }
+  const int rows = size - r0 < VR ? size - r0 : VR;
+  float* ob = out + (int64_t)b * 3 * size * size;
+  for (int item = threadIdx.x; item < rows * size; item += 256) {
+    const int rr = item / size, c = item - rr * size;
+    Taps t = {};
+    if (!in_lds) t = make_taps(ay, r0 + rr + g.top);
+    const int xmin = in_lds ? s_xmin[rr] : t.xmin, n = in_lds ? s_n[rr] : t.n;
+    const uint8_t* p = src + ((int64_t)xmin * size + c) * 3;
+    int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+#pragma unroll 4
+    for (int x = 0; x < n - 1; ++x) mac_px(load_px4(p + (int64_t)x * size * 3), in_lds ? coef[rr][x] : tap_coeff(ay, t, x), a0, a1, a2);
+    if (n > 0) {
+      const int x = n - 1, k = in_lds ? coef[rr][x] : tap_coeff(ay, t, x);
+      const uint8_t* q = p + (int64_t)x * size * 3;
+      a0 += q[0] * k;
+      a1 += q[1] * k;
+      a2 += q[2] * k;
+    }
+    // ToTensor (x / 255 in fp32) and Normalize ((x - mean) / std), correctly rounded divisions
+    const int64_t o = (int64_t)(r0 + rr) * size + c;
+    ob[o] = __fdiv_rn(__fdiv_rn((float)clip8(a0), 255.0f) - m0, s0);
+    ob[o + (int64_t)size * size] = __fdiv_rn(__fdiv_rn((float)clip8(a1), 255.0f) - m1, s1);
+    ob[o + 2 * (int64_t)size * size] = __fdiv_rn(__fdiv_rn((float)clip8(a2), 255.0f) - m2, s2);
+  }
+}
+
+}  // namespace
+
+hipError_t launch_preprocess_u8(const uint8_t* pixels, const int64_t* desc, int32_t B, int32_t size, const float* mean_std,
+                                uint8_t* ws, float* out, hipStream_t s) {
+  resample_h_kernel<<<dim3((size + 31) / 32, B, 1), 256, 0, s>>>(pixels, desc, size, ws);
+  resample_v_normalize_kernel<<<dim3((size + VR - 1) / VR, B), 256, 0, s>>>(desc, size, ws, mean_std[0], mean_std[1], mean_std[2],
+                                                                      mean_std[3], mean_std[4], mean_std[5], out);
+  return hipGetLastError();
+}
+
+}  // namespace tapclip

@@ -853,6 +853,16 @@ int tapclip_logits(const float* img, const float* txt, float scale, int32_t B, i
   return TAPCLIP_OK;
 }
 
+int tapclip_preprocess_u8(const uint8_t* pixels, const int64_t* desc, int32_t B, int32_t size, const float* mean_std,
+                          void* workspace, float* out, tapclip_stream_t stream) {
+  if (!pixels || !desc || !mean_std || !workspace || !out) return fail(TAPCLIP_EINVAL, "null argument");
+  if (B <= 0 || B > 65535 || size <= 0 || size > 4096) return fail(TAPCLIP_EINVAL, "preprocess needs 0 < B <= 65535 and 0 < size <= 4096 (got %d, %d)", B, size);
+  for (int i = 3; i < 6; ++i)
+    if (!(mean_std[i] > 0.f)) return fail(TAPCLIP_EINVAL, "preprocess: std[%d] must be positive", i - 3);
+  HIP_TRY(launch_preprocess_u8(pixels, desc, B, size, mean_std, static_cast<uint8_t*>(workspace), out, static_cast<hipStream_t>(stream)));
+  return TAPCLIP_OK;
+}
+
 int tapclip_layernorm_f32(const float* x, const float* gamma, const float* beta, int64_t rows, int32_t d, float* y,
                           tapclip_stream_t stream) {
   if (!x || !gamma || !beta || !y) return fail(TAPCLIP_EINVAL, "null argument");

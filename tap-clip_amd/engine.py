@@ -324,6 +324,54 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def preprocess_u8(images, size: int = 224, device="cuda", mean=CLIP_MEAN, std=CLIP_STD) -> torch.Tensor:
+    """CLIP's eval transform on the GPU (include/tapclip.h tapclip_preprocess_u8; the reference applies
+    `clip.get_preprocess()` per sample on the CPU, dataset.py:29-35): a list of decoded RGB images -- uint8
+    [h, w, 3] tensors / arrays or PIL images, any sizes -> [B, 3, size, size] fp32 on `device`.  Bit-identical
+    to Pillow's bicubic resize + torchvision's CenterCrop / ToTensor / Normalize."""
+    import numpy as np
+
+    dev = torch.device(device)
+    flat, dims = [], []
+    for im in images:
+        if not torch.is_tensor(im):
+            im = torch.from_numpy(np.array(im.convert("RGB") if hasattr(im, "convert") else im))
+        if im.dtype != torch.uint8 or im.dim() != 3 or im.shape[2] != 3:
+            raise ValueError(f"preprocess_u8 takes uint8 [h, w, 3] images, got {im.dtype} {tuple(im.shape)}")
+        if im.shape[0] == 0 or im.shape[1] == 0:
+            raise ValueError("preprocess_u8: empty image")
+        dims.append((int(im.shape[0]), int(im.shape[1])))
+        flat.append(im.contiguous().view(-1))
+    if not flat:
+        raise ValueError("preprocess_u8: no images")
+    on_dev = all(f.device == dev for f in flat)
+    desc, pix_off, ws_off = [], 0, 0
+    if on_dev:  # no packing copy: the descriptor's offsets are address differences to the first image
+        pixels = flat[0]
+        offs = [f.data_ptr() - pixels.data_ptr() for f in flat]
+    else:
+        pixels = torch.cat([f.cpu() for f in flat]).to(dev, non_blocking=True)
+        offs = []
+        for h, w in dims:
+            offs.append(pix_off)
+            pix_off += h * w * 3
+    for (h, w), o in zip(dims, offs):
+        desc.append((o, h, w, ws_off))
+        ws_off += h * size * 3
+    desc_t = torch.tensor(desc, dtype=torch.int64).to(dev, non_blocking=True)
+    ws = torch.empty(ws_off, dtype=torch.uint8, device=dev)
+    out = torch.empty(len(dims), 3, size, size, dtype=torch.float32, device=dev)
+    ms = (C.c_float * 6)(*[float(v) for v in mean], *[float(v) for v in std])
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().tapclip_preprocess_u8(_ptr(pixels), _ptr(desc_t), len(dims), size, ms, _ptr(ws), _ptr(out),
+                                                     _stream_ptr(dev)))
+    return out
+
+
 def mx8_quantize(x: torch.Tensor):
     """fp32 [rows, K] -> (e4m3 bytes [rows, K], e8m0 scale bytes [K/64, rows_pad, 2]): the fp8 path's operand
     format (include/tapclip.h tapclip_mx8_quantize)."""

@@ -137,24 +137,39 @@ class HashTokenizer:
 
 
 def _make_preprocess(size: int) -> Callable:
-    """CLIP eval transform (resize shorter side bicubic -> centre crop -> normalise) on tensors /
-    PIL images, without torchvision."""
+    """CLIP's eval transform without torchvision: Resize(size, bicubic) with torchvision's size rule (shorter
+    side -> size, longer side int(size * long / short)), CenterCrop(size) (origin int(round((n - size) / 2.0))),
+    ToTensor, Normalize.  PIL images and uint8 [h, w, 3] arrays go through Pillow's own 8-bit bicubic resize --
+    what the reference's transform does on the CPU; `engine.preprocess_u8` is the same, bit for bit, on the GPU --
+    float [3, h, w] tensors through torch's antialiased bicubic."""
     mean = torch.tensor([0.48145466, 0.4578275, 0.40821073]).view(3, 1, 1)
     std = torch.tensor([0.26862954, 0.26130258, 0.27577711]).view(3, 1, 1)
 
-    def preprocess(img) -> torch.Tensor:
-        if not torch.is_tensor(img):
-            import numpy as np
+    def geometry(h: int, w: int):
+        nh, nw = (int(size * h / w), size) if w <= h else (size, int(size * w / h))
+        return nh, nw, int(round((nh - size) / 2.0)), int(round((nw - size) / 2.0))
 
-            arr = np.asarray(img.convert("RGB") if hasattr(img, "convert") else img)
-            img = torch.from_numpy(arr.copy()).permute(2, 0, 1)
+    def preprocess(img) -> torch.Tensor:
+        import numpy as np
+
+        if not torch.is_tensor(img) or (img.dtype == torch.uint8 and img.dim() == 3 and img.shape[-1] == 3):
+            from PIL import Image
+
+            if torch.is_tensor(img):
+                img = Image.fromarray(img.cpu().numpy())
+            elif not hasattr(img, "resize"):
+                img = Image.fromarray(np.asarray(img))
+            img = img.convert("RGB")
+            w, h = img.size
+            nh, nw, top, left = geometry(h, w)
+            arr = np.asarray(img.resize((nw, nh), Image.BICUBIC))[top: top + size, left: left + size]
+            x = torch.from_numpy(arr.copy()).permute(2, 0, 1).to(torch.float32).div(255)
+            return x.sub(mean).div(std)
         x = img.float() / 255.0 if img.dtype == torch.uint8 else img.float()
         _, h, w = x.shape
-        s = size / min(h, w)
-        nh, nw = max(size, round(h * s)), max(size, round(w * s))
+        nh, nw, top, left = geometry(h, w)
         x = torch.nn.functional.interpolate(x[None], size=(nh, nw), mode="bicubic", align_corners=False,
                                             antialias=True)[0].clamp_(0, 1)
-        top, left = (nh - size) // 2, (nw - size) // 2
         x = x[:, top: top + size, left: left + size]
         return (x - mean) / std
 

@@ -1,0 +1,91 @@
+"""The input side: `clip.get_preprocess()`'s eval transform.
+
+CPU tests pin oracle/preprocess_ref.py -- a restatement of Pillow's 8-bit bicubic resampling -- against Pillow
+itself, BIT-EXACTLY (Pillow is the library the reference's transform calls for its PIL images, and it is installed
+here), and the float tail against torch CPU ops.  GPU tests compare tapclip_preprocess_u8 (through the C ABI) with
+the oracle: bit-exact, integer work and correctly rounded fp32 divisions."""
+import numpy as np
+import pytest
+import torch
+
+import tap_clip_amd  # noqa: F401
+from oracle import preprocess_ref as P
+
+Image = pytest.importorskip("PIL.Image")
+
+# (h, w, size): down- and up-scales, odd sizes, square, 1-pixel-wide, taps beyond the kernel's LDS table (scale > 32)
+CASES = [(375, 500, 224), (500, 375, 224), (224, 224, 224), (100, 80, 224), (37, 53, 48), (231, 229, 224), (64, 64, 224),
+         (3, 5, 16), (1, 40, 8), (40, 1, 8), (600, 800, 336), (24, 1000, 24), (1000, 24, 24)]
+
+
+def _img(h, w, seed):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    if seed % 2:  # smooth images too: long runs exercise the rounding, noise the clipping
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = np.stack([(yy * 255 // max(h - 1, 1)), (xx * 255 // max(w - 1, 1)), ((yy + xx) % 256)], -1).astype(np.uint8)
+    return base
+
+
+@pytest.mark.parametrize("h,w,size", CASES)
+def test_oracle_resize_is_pillow_bit_exact(h, w, size):
+    img = _img(h, w, h * 7 + w)
+    nh, nw = P.resized_size(h, w, size)
+    assert min(nh, nw) == size
+    ref = np.asarray(Image.fromarray(img).resize((nw, nh), Image.BICUBIC))
+    assert np.array_equal(P.resize_bicubic_u8(img, nh, nw), ref)
+
+
+def test_oracle_transform_matches_pillow_plus_torch_ops():
+    img = _img(375, 500, 3)
+    nh, nw = P.resized_size(375, 500, 224)
+    assert (nh, nw) == (224, 298)
+    top, left = P.crop_origin(nh, nw, 224)
+    assert (top, left) == (0, 37)
+    assert P.crop_origin(299, 224, 224) == (38, 0)  # 37.5 rounds to even
+    r = np.asarray(Image.fromarray(img).resize((nw, nh), Image.BICUBIC))[top: top + 224, left: left + 224]
+    x = torch.from_numpy(r.copy()).permute(2, 0, 1).to(torch.float32).div(255)
+    x = x.sub(torch.tensor(P.CLIP_MEAN).view(3, 1, 1)).div(torch.tensor(P.CLIP_STD).view(3, 1, 1))
+    assert np.array_equal(P.clip_preprocess(img, 224), x.numpy())
+
+
+def test_wrapper_preprocess_follows_the_same_transform():
+    """CLIPWrapper.get_preprocess() on a PIL image (the CPU path the dataset workers run, as the reference's)"""
+    from tap_clip_amd.models.clip_wrapper import _make_preprocess
+
+    img = _img(120, 90, 5)
+    out = _make_preprocess(64)(Image.fromarray(img))
+    assert out.shape == (3, 64, 64) and out.dtype == torch.float32
+    assert np.array_equal(out.numpy(), P.clip_preprocess(img, 64))
+
+
+@pytest.mark.gpu
+def test_gpu_preprocess_bit_exact_mixed_batch():
+    from tap_clip_amd import engine
+
+    imgs = [_img(h, w, h * 7 + w) for h, w, _ in CASES]
+    for size in (224, 48):
+        out = engine.preprocess_u8(imgs, size=size).cpu().numpy()
+        assert out.shape == (len(imgs), 3, size, size)
+        for i, im in enumerate(imgs):
+            ref = P.clip_preprocess(im, size)
+            assert np.array_equal(out[i], ref), f"image {i} {im.shape} size {size}: max diff {np.abs(out[i] - ref).max()}"
+
+
+@pytest.mark.gpu
+def test_gpu_preprocess_matches_pillow_directly_and_feeds_the_tower():
+    from tap_clip_amd import engine
+
+    img = _img(333, 517, 11)
+    pil = Image.fromarray(img)
+    out = engine.preprocess_u8([pil, torch.from_numpy(img).cuda()], size=224)
+    nh, nw = P.resized_size(333, 517, 224)
+    top, left = P.crop_origin(nh, nw, 224)
+    r = np.asarray(pil.resize((nw, nh), Image.BICUBIC))[top: top + 224, left: left + 224]
+    x = torch.from_numpy(r.copy()).permute(2, 0, 1).to(torch.float32).div(255)
+    x = x.sub(torch.tensor(P.CLIP_MEAN).view(3, 1, 1)).div(torch.tensor(P.CLIP_STD).view(3, 1, 1))
+    assert torch.equal(out[0].cpu(), x) and torch.equal(out[1].cpu(), x)
+    with pytest.raises(ValueError):
+        engine.preprocess_u8([torch.zeros(4, 4, 3)])  # not uint8
+    with pytest.raises(ValueError):
+        engine.preprocess_u8([])
