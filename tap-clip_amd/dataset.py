@@ -60,10 +60,46 @@ class RelabeledSubset(Dataset):
         return image, self.label_map[raw_label]
 
 
+def _raw_u8(img) -> torch.Tensor:
+    """decoded RGB image -> uint8 [h, w, 3] (what `engine.preprocess_u8` takes)"""
+    import numpy as np
+
+    return torch.from_numpy(np.array(img))
+
+
+def _collate_raw(batch):
+    images, labels = zip(*batch)  # images keep their own sizes: a list, not a stacked tensor
+    return list(images), torch.tensor(labels, dtype=torch.int64)
+
+
+class GpuPreprocessLoader:
+    """Wraps a loader of (list of uint8 photos, labels) batches: the eval transform runs on the GPU, one
+    `tapclip_preprocess_u8` call per batch, and the loop body sees the same `(images [B,3,S,S] fp32, labels)`
+    pairs -- bit-identical values -- as with `preprocess=clip.get_preprocess()` in the workers."""
+
+    def __init__(self, loader: DataLoader, size: int, device="cuda"):
+        self.loader, self.size, self.device = loader, size, torch.device(device)
+        self.dataset = loader.dataset
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        from . import engine
+
+        for photos, labels in self.loader:
+            yield engine.preprocess_u8(photos, size=self.size, device=self.device), labels.to(self.device, non_blocking=True)
+
+
 def get_dataloaders(root_dir="data/OfficeHomeDataset_10072016/Real_World", class_names=None, batch_size=32,
-                    num_shots=5, preprocess=None, *, num_workers: int = 4, seed: Optional[int] = None):
+                    num_shots=5, preprocess=None, *, num_workers: int = 4, seed: Optional[int] = None,
+                    gpu_preprocess: Optional[int] = None, device="cuda"):
+    """`gpu_preprocess=S` (instead of `preprocess=`): the workers only decode; resize / crop / normalise to S x S
+    run on `device` per batch (`GpuPreprocessLoader`)."""
     rng = random.Random(seed) if seed is not None else random
-    full = ImageFolder(root_dir, transform=preprocess)
+    if gpu_preprocess is not None and preprocess is not None:
+        raise ValueError("give either preprocess= (CPU, per sample) or gpu_preprocess=<size>, not both")
+    full = ImageFolder(root_dir, transform=_raw_u8 if gpu_preprocess is not None else preprocess)
     raw_to_new = {full.class_to_idx[name]: i for i, name in enumerate(class_names)}  # KeyError for an unknown class, like the reference
     by_label = defaultdict(list)
     for idx, (_, label) in enumerate(full.samples):  # from the sample list: no image is decoded here
@@ -84,8 +120,13 @@ def get_dataloaders(root_dir="data/OfficeHomeDataset_10072016/Real_World", class
 
     train_set = RelabeledSubset(full, train_idx, raw_to_new)
     val_set = RelabeledSubset(full, val_idx, raw_to_new)
-    train_loader = None if num_shots == 0 else DataLoader(train_set, batch_size=batch_size, shuffle=True, num_workers=num_workers)
-    val_loader = DataLoader(val_set, batch_size=batch_size, shuffle=False, num_workers=num_workers)
+    collate = _collate_raw if gpu_preprocess is not None else None
+    train_loader = None if num_shots == 0 else DataLoader(train_set, batch_size=batch_size, shuffle=True, num_workers=num_workers,
+                                                          collate_fn=collate)
+    val_loader = DataLoader(val_set, batch_size=batch_size, shuffle=False, num_workers=num_workers, collate_fn=collate)
+    if gpu_preprocess is not None:
+        train_loader = None if train_loader is None else GpuPreprocessLoader(train_loader, gpu_preprocess, device)
+        val_loader = GpuPreprocessLoader(val_loader, gpu_preprocess, device)
     print("Raw -> New Label Map:", raw_to_new)
     print("Total Classes (Prompt):", len(class_names))
     return train_loader, val_loader

@@ -89,3 +89,42 @@ def test_gpu_preprocess_matches_pillow_directly_and_feeds_the_tower():
         engine.preprocess_u8([torch.zeros(4, 4, 3)])  # not uint8
     with pytest.raises(ValueError):
         engine.preprocess_u8([])
+
+
+def _photo_folder(root):
+    rng = np.random.default_rng(3)
+    for cls in ["Backpack", "Mug", "Pen"]:
+        (root / cls).mkdir(parents=True)
+        for k in range(5):
+            h, w = int(rng.integers(40, 200)), int(rng.integers(40, 200))
+            Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(root / cls / f"{k}.png")
+
+
+def test_raw_loader_hands_over_decoded_photos(tmp_path):
+    """gpu_preprocess= leaves resize / crop / normalise to the device: workers return the decoded uint8 photos"""
+    from tap_clip_amd.dataset import get_dataloaders
+
+    _photo_folder(tmp_path / "rw")
+    _, val = get_dataloaders(str(tmp_path / "rw"), ["Pen", "Mug"], batch_size=4, num_shots=1, gpu_preprocess=32, num_workers=0, seed=0)
+    photos, labels = next(iter(val.loader))
+    assert isinstance(photos, list) and len(photos) == 4 and labels.dtype == torch.int64
+    assert all(p.dtype == torch.uint8 and p.dim() == 3 and p.shape[2] == 3 for p in photos)
+    with pytest.raises(ValueError):
+        get_dataloaders(str(tmp_path / "rw"), ["Pen"], preprocess=lambda x: x, gpu_preprocess=32, num_workers=0)
+
+
+@pytest.mark.gpu
+def test_gpu_loader_batches_equal_cpu_loader_batches(tmp_path):
+    from tap_clip_amd.dataset import get_dataloaders
+    from tap_clip_amd.models.clip_wrapper import _make_preprocess
+
+    _photo_folder(tmp_path / "rw")
+    names = ["Pen", "Backpack", "Mug"]
+    _, val_cpu = get_dataloaders(str(tmp_path / "rw"), names, batch_size=5, num_shots=1, preprocess=_make_preprocess(64), num_workers=0, seed=1)
+    _, val_gpu = get_dataloaders(str(tmp_path / "rw"), names, batch_size=5, num_shots=1, gpu_preprocess=64, num_workers=0, seed=1)
+    assert len(val_cpu) == len(val_gpu)
+    n = 0
+    for (xc, yc), (xg, yg) in zip(val_cpu, val_gpu):
+        assert xg.is_cuda and torch.equal(xc, xg.cpu()) and torch.equal(yc, yg.cpu())
+        n += len(yc)
+    assert n == 12
