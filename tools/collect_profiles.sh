@@ -1,0 +1,28 @@
+#!/bin/bash
+# Collects the round's profile set on the GPU box (run through gpurun from the repo root):
+#   tools/collect_profiles.sh <tag>     -> gpurun_out/prof_<tag>/..., summaries copied by hand into profiles/
+set -e
+TAG=${1:-r01}
+R=$PWD
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+FAST="--steps 3 --warmup 1 --no-cpu-baseline --no-full-forward --no-kernel-events --no-precisions --no-input-side"
+python3 $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+echo "bench done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $R/bench.py > $OUT/bench_under_trace.json 2> $OUT/stats.err
+echo "trace done"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- python3 $R/bench.py $FAST > /dev/null 2> $OUT/fetch.err
+echo "fetch done"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- python3 $R/bench.py $FAST > /dev/null 2> $OUT/write.err
+echo "write done"
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/sq -o sq -- python3 $R/bench.py $FAST > /dev/null 2> $OUT/sq.err
+echo "sq done"
+cd $R
+python3 tools/trace_family.py $OUT/stats $OUT/gemm_family_trace_summary.json bf16
+python3 tools/pmc_traffic.py $OUT/fetch $OUT/write $OUT/pmc_traffic_bench.json
+python3 tools/pmc_sq.py $OUT/sq $OUT/pmc_sq_bench.json
+cp $(ls $OUT/stats/*kernel_stats.csv $OUT/stats/*/*kernel_stats.csv 2>/dev/null | head -n 1) $OUT/kernel_stats_bench.csv
+# the raw traces are large: keep the summaries only
+rm -rf $OUT/stats/*/*kernel_trace.csv $OUT/stats/*kernel_trace.csv $OUT/fetch $OUT/write $OUT/sq
+echo "summaries done"
