@@ -128,3 +128,32 @@ def test_gpu_loader_batches_equal_cpu_loader_batches(tmp_path):
         assert xg.is_cuda and torch.equal(xc, xg.cpu()) and torch.equal(yc, yg.cpu())
         n += len(yc)
     assert n == 12
+
+
+def test_oracle_resize_random_geometries_pillow_bit_exact():
+    """40 seeded random (h, w, size) triples, aspect ratios up to 12:1, sizes 8..96: oracle == Pillow, every byte"""
+    rng = np.random.default_rng(2024)
+    for k in range(40):
+        size = int(rng.integers(8, 97))
+        h = int(rng.integers(1, 400))
+        w = int(np.clip(h * float(rng.uniform(1 / 12, 12)), 1, 600))
+        img = _img(h, w, k)
+        nh, nw = P.resized_size(h, w, size)
+        ref = np.asarray(Image.fromarray(img).resize((nw, nh), Image.BICUBIC))
+        assert np.array_equal(P.resize_bicubic_u8(img, nh, nw), ref), (h, w, size)
+
+
+@pytest.mark.gpu
+def test_gpu_preprocess_random_geometries_bit_exact():
+    from tap_clip_amd import engine
+
+    rng = np.random.default_rng(7)
+    for size in (32, 96):
+        imgs = []
+        for k in range(24):
+            h = int(rng.integers(1, 300))
+            w = int(np.clip(h * float(rng.uniform(1 / 10, 10)), 1, 500))
+            imgs.append(_img(h, w, k))
+        out = engine.preprocess_u8(imgs, size=size).cpu().numpy()
+        for i, im in enumerate(imgs):
+            assert np.array_equal(out[i], P.clip_preprocess(im, size)), (im.shape, size)
