@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <string>
 #include <vector>
 
 #include "../tap-clip_amd/csrc/kernels.h"
@@ -46,7 +47,19 @@ int main(int argc, char** argv) {
   const int iters = argc > 1 ? atoi(argv[1]) : 20;
   const int64_t M = argc > 2 ? atoll(argv[2]) : 50432;
   struct Shape { const char* name; int N, K, epi; };
-  const Shape shapes[] = {
+  const bool text = argc > 3 && std::string(argv[3]) == "text";  // the text tower's shapes (run with M = 6045)
+  const Shape text_shapes[] = {
+      {"t_qkv    N1536 K512  bias->bf16 ", 1536, 512, EPI_BIAS_BF16},
+      {"t_out    N512  K512  bias->bf16 ", 512, 512, EPI_BIAS_BF16},
+      {"t_fc     N2048 K512  gelu->bf16 ", 2048, 512, EPI_BIAS_GELU_BF16},
+      {"t_proj   N512  K2048 bias->bf16 ", 512, 2048, EPI_BIAS_BF16},
+      {"t_qkv-like N1536 K1024          ", 1536, 1024, EPI_BIAS_BF16},  // slope/intercept probes
+      {"t_qkv-like N1536 K2048          ", 1536, 2048, EPI_BIAS_BF16},
+      {"t_qkv-like N1536 K128           ", 1536, 128, EPI_BIAS_BF16},
+      {"t_out-like N512  K128           ", 512, 128, EPI_BIAS_BF16},
+      {"t_out-like N512  K1024          ", 512, 1024, EPI_BIAS_BF16},
+  };
+  const Shape image_shapes[] = {
       {"qkv      N2304 K768  bias->bf16 ", 2304, 768, EPI_BIAS_BF16},
       {"out_proj N768  K768  bias->bf16 ", 768, 768, EPI_BIAS_BF16},
       {"fc_gelu  N3072 K768  gelu->bf16 ", 3072, 768, EPI_BIAS_GELU_BF16},
@@ -57,6 +70,7 @@ int main(int argc, char** argv) {
       {"qkv-like N2304 K3072 bias->bf16 ", 2304, 3072, EPI_BIAS_BF16},   // slope/intercept probe
       {"qkv-like N2304 K1536 bias->bf16 ", 2304, 1536, EPI_BIAS_BF16},
   };
+  const Shape* shapes = text ? text_shapes : image_shapes;
   bf16_t* A = rand_bf16((size_t)M * 3072, 1, 1.0f);
   bf16_t* W = rand_bf16((size_t)3072 * 3072, 2, 0.03f);
   float* bias;
@@ -75,7 +89,7 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   // interleaved rounds in ONE process (guide rule 24): every round times each shape once; report median / min
-  const int n_shapes = sizeof(shapes) / sizeof(shapes[0]);
+  const int n_shapes = text ? (int)(sizeof(text_shapes) / sizeof(text_shapes[0])) : (int)(sizeof(image_shapes) / sizeof(image_shapes[0]));
   std::vector<std::vector<float>> times(n_shapes);
   auto run = [&](const Shape& sh, int reps) {
     GemmArgs g;
@@ -103,8 +117,8 @@ int main(int argc, char** argv) {
       times[k].push_back(ms / 4);
     }
   }
-  // ---- attention core at the image tower's shape
-  {
+  // ---- attention core at the image tower's shape (buffers are sized for M = 50 432: not in the text mode)
+  if (!text && M >= 64 * 577) {
     AttnArgs a;
     a.qkv_hi = A; a.qkv_lo = nullptr; a.out_hi = obf; a.out_lo = nullptr; a.probs = nullptr;
     a.n_seq = (int)(M / 197); a.T = 197; a.H = 12; a.D = 768; a.causal = 0;
@@ -122,7 +136,7 @@ int main(int argc, char** argv) {
     std::sort(t.begin(), t.end());
     printf("attention n%d T197 H12: median %8.1f us  min %8.1f us\n", a.n_seq, 1e3 * t[t.size() / 2], 1e3 * t[0]);
   }
-  {  // ViT-L/14@336 attention: 577 tokens, 16 heads (flash-style kernel)
+  if (!text && M >= 64 * 577) {  // ViT-L/14@336 attention: 577 tokens, 16 heads (flash-style kernel)
     AttnArgs a;
     a.qkv_hi = A; a.qkv_lo = nullptr; a.out_hi = obf; a.out_lo = nullptr; a.probs = nullptr;
     a.n_seq = 64; a.T = 577; a.H = 16; a.D = 1024; a.causal = 0;
