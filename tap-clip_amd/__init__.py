@@ -7,10 +7,13 @@ from . import configs, synth  # noqa: F401  (pure host-side helpers, importable 
 __all__ = ["configs", "synth", "engine", "models", "dist"]
 
 
-def install_as_models() -> None:
+def install_as_models(host_side: bool = False) -> None:
     """Make the reference's own import lines resolve to this package:
     `from models.clip_wrapper import CLIPWrapper`, `from models.model_wrapper import FullModel`
-    (reference train.py:3-4, test_cross_domain.py:4-5) then need no edit at all."""
+    (reference train.py:3-4, test_cross_domain.py:4-5) then need no edit at all.
+    `host_side=True` also takes over `from dataset import get_dataloaders` and `from utils.eval_metrics import ...`
+    (train.py:5-6): the torchvision-free loader (with its `gpu_preprocess=` option) and the evaluation functions
+    that count on the device."""
     import importlib
     import sys
 
@@ -18,6 +21,10 @@ def install_as_models() -> None:
     sys.modules["models"] = pkg
     for sub in ("clip_wrapper", "model_wrapper", "prompt_learner", "attribution_monitor", "prompt_adjustor"):
         sys.modules[f"models.{sub}"] = importlib.import_module(f"{__name__}.models.{sub}")
+    if host_side:
+        sys.modules["dataset"] = importlib.import_module(f"{__name__}.dataset")
+        sys.modules["utils"] = importlib.import_module(f"{__name__}.utils")
+        sys.modules["utils.eval_metrics"] = importlib.import_module(f"{__name__}.utils.eval_metrics")
 
 
 def __getattr__(name):

@@ -118,3 +118,29 @@ def test_bpe_tokenizer_algorithm(tmp_path):
     assert body[4:6] == [enc["a</w>"], enc["mug</w>"]] and body[6] == tok.eot
     long = tok("mug " * 20)
     assert long[0, -1] == tok.eot and long.shape == (1, 8)  # truncated, EOT kept
+
+
+def test_install_as_models_resolves_the_reference_import_lines():
+    """reference train.py:3-6 / test_cross_domain.py:4-5: `from models... import`, `from dataset import`,
+    `from utils.eval_metrics import` resolve to this package after install_as_models(host_side=True)"""
+    import subprocess
+    import sys
+
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import tap_clip_amd
+tap_clip_amd.install_as_models(host_side=True)
+from models.model_wrapper import FullModel
+from models.clip_wrapper import CLIPWrapper
+from models.prompt_learner import PromptLearner
+from models.attribution_monitor import AttributionMonitor
+from models.prompt_adjustor import PromptAdjustor
+from dataset import get_dataloaders
+from utils.eval_metrics import evaluate_accuracy, evaluate_per_class_accuracy
+assert FullModel.__module__.startswith("tap_clip_amd") and get_dataloaders.__module__.startswith("tap_clip_amd")
+assert evaluate_accuracy.__module__.startswith("tap_clip_amd")
+print("ok")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
