@@ -157,3 +157,48 @@ def test_gpu_preprocess_random_geometries_bit_exact():
         out = engine.preprocess_u8(imgs, size=size).cpu().numpy()
         for i, im in enumerate(imgs):
             assert np.array_equal(out[i], P.clip_preprocess(im, size)), (im.shape, size)
+
+
+@pytest.mark.gpu
+def test_script_flow_loader_to_accuracy(tmp_path, capsys):
+    """The flow of the reference's train.py (54-67, 99-116) end to end on the package: few-shot loaders with the
+    transform on the GPU -> FullModel on the tiny towers -> AdamW on the context bank -> evaluate_accuracy.
+    Each class folder holds one flat colour (plus noise), so a few prompt-tuning steps must fit the 2-shot set."""
+    from tap_clip_amd import configs, synth
+    from tap_clip_amd.dataset import get_dataloaders
+    from tap_clip_amd.models import CLIPWrapper, FullModel
+    from tap_clip_amd.utils.eval_metrics import evaluate_accuracy, evaluate_per_class_accuracy
+
+    names = ["Backpack", "Mug", "Pen"]
+    rng = np.random.default_rng(0)
+    colours = {"Backpack": (220, 30, 30), "Mug": (30, 220, 30), "Pen": (30, 30, 220)}
+    for cls in names:
+        (tmp_path / "rw" / cls).mkdir(parents=True)
+        for k in range(6):
+            h, w = int(rng.integers(40, 90)), int(rng.integers(40, 90))
+            img = np.clip(np.asarray(colours[cls])[None, None, :] + rng.integers(-25, 26, (h, w, 3)), 0, 255).astype(np.uint8)
+            Image.fromarray(img).save(tmp_path / "rw" / cls / f"{k}.png")
+    cfg = configs.get_config("tiny")
+    clip = CLIPWrapper("tiny", None, "cuda", precision="bf16", state_dict=synth.make_state_dict(cfg, seed=3))
+    train, val = get_dataloaders(str(tmp_path / "rw"), names, batch_size=6, num_shots=2, gpu_preprocess=cfg.image_size,
+                                 num_workers=0, seed=0)
+    model = FullModel(names, clip, prompt_len=4, class_specific=True)
+    opt = torch.optim.AdamW(model.prompt_learner.parameters(), lr=5e-2)
+    first = last = None
+    for epoch in range(25):
+        model.train()
+        for images, labels in train:
+            assert images.is_cuda and images.shape[1:] == (3, cfg.image_size, cfg.image_size)
+            out = model(images, labels)
+            opt.zero_grad()
+            out["loss"].backward()
+            opt.step()
+            last = float(out["loss"].detach())
+            first = last if first is None else first
+    assert last < first, (first, last)
+    model.eval()
+    acc = evaluate_accuracy(model, val, "cuda")
+    per = evaluate_per_class_accuracy(model, val, "cuda", names)
+    assert 0.0 <= acc <= 100.0 and set(per) == set(names)
+    assert "Overall Accuracy" in capsys.readouterr().out
+    assert acc >= 66.0, (acc, per)  # colours are linearly separable: the tuned prompts must get most of 12 images right
