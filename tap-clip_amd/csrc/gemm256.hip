@@ -7,8 +7,10 @@
 // reference call site models/clip_wrapper.py:47) at M = batch x 197 rows.
 //
 // Design notes (all measured on MI355X, profiles/ r01):
-//  * tile size: a CU's MFMA peak is ~4070 FLOP/clk against ~56 B/clk from L2, so a tile needs >= 73
-//    FLOP per staged byte; 128 x 128 gives 64, 256 x 128 gives 85, 256 x 256 gives 128.
+//  * tile size: a CU's MFMA peak is ~4070 FLOP/clk; its vector-memory path delivered ~19 B/clk of LDS-DMA in this
+//    kernel (32 one-KiB pieces per k-step at ~55 cycles each; all-L2-hit diagnostic: 15 % faster),
+//    so FLOP per staged byte decides: 128 x 128 gives 64, 256 x 128 gives 85, 256 x 256 gives 128 (the largest
+//    tile 8 waves x 256 registers hold).
 //  * persistent + ring: one workgroup per CU walks its XCD's run of tiles; the K steps of successive
 //    output tiles form ONE linear sequence through the ring, NS - 1 steps are always in flight, and the
 //    waits are hand-counted s_waitcnt vmcnt(N) with raw s_barrier (vmcnt counts loads, stores and LDS-DMA
