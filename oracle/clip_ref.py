@@ -112,9 +112,23 @@ def _rq(x: torch.Tensor, emulate: Optional[str]) -> torch.Tensor:
     return _rb(x, emulate)
 
 
-def _act(x: torch.Tensor, quick: bool) -> torch.Tensor:
+def gelu_fit(x: torch.Tensor) -> torch.Tensor:
+    """The GELU of the 16-/8-bit fast paths (tap-clip_amd/csrc/common.h gelu_erf_fast): x * sigmoid(x * (a + b x^2 +
+    c x^4)) fitted to the exact-erf GELU, max |error| 2.5e-5.  Only used under `emulate`: that error is 1-6 % of a
+    bf16 ulp of the stored value, so against the exact form a few per cent of the MLP-hidden elements round the
+    other way (each a full 2^-8 relative step) -- the 3e-3 per-block rel-max of the round-1 log came from there."""
+    xc = x.clamp(-10.0, 10.0)
+    x2 = xc * xc
+    p = 1.0142631e-3 * x2 - 1.0677573e-1
+    p = p * x2 - 2.3011213
+    return x / (1.0 + torch.exp2(p * xc))
+
+
+def _act(x: torch.Tensor, quick: bool, emulate: Optional[str] = None) -> torch.Tensor:
     if quick:
         return x * torch.sigmoid(1.702 * x)
+    if emulate is not None:
+        return gelu_fit(x)
     return F.gelu(x)  # exact erf form, nn.GELU() default
 
 
@@ -176,7 +190,7 @@ def block_forward(
 
     h = F.layer_norm(x, (D,), g("ln_2.weight"), g("ln_2.bias"), 1e-5)
     h = F.linear(_rq(h, emulate), _rq(g("mlp.c_fc.weight"), emulate), g("mlp.c_fc.bias"))
-    h = _act(h, quick_gelu)
+    h = _act(h, quick_gelu, emulate)
     if taps is not None:
         taps["mlp_hidden"] = h
     h = F.linear(_rq(h, emulate), _rq(g("mlp.c_proj.weight"), emulate), g("mlp.c_proj.bias"))

@@ -160,9 +160,166 @@ def g_image_tower(ref):
         _save(f"image_tower_{name}", seed_weights=2, seed_images=0, batch=2, embeddings=emb)
 
 
+def _seed_context(model, class_names, cfg, prompt_len, seed):
+    """Replace the torch.randn context draw by the build's own seeded generator, so that large cases commit a seed
+    instead of the [n_cls, P, D] tensor (any N(0,1) sample is the same workload: prompt_learner.py:41)."""
+    ctx = synth.make_prompts(len(class_names), prompt_len, cfg, seed=seed)[0]
+    with torch.no_grad():
+        for i, c in enumerate(class_names):
+            model.prompt_learner.context_bank[c].copy_(ctx[i])
+    return ctx
+
+
+def g_fullmodel_b16_c65(ref):
+    """BASELINE.json configs[2] at the reference's own loop: ViT-B/16 image + text towers, 65 classes, 16 context
+    tokens (T = 93), attention-map capture on, batch 4 (the literal loop is 65 x (B + 1) text passes)."""
+    cfg = clip_ref.CONFIGS["ViT-B-16"]
+    sd = synth.make_state_dict(cfg, seed=2)
+    names = class_list(65)
+    P, B, KEEP = 16, 4, 8
+    table = token_table(names, cfg)
+    images = synth.make_images(B, cfg, 0)
+    labels = synth.make_labels(B, len(names))
+    for semantics in ("literal", "intended"):
+        t0 = time.time()
+        clip = ref_harness.RefClip(cfg, sd, semantics, ref_harness.FixedTokenizer(table))
+        torch.manual_seed(1234)
+        model = ref["FullModel"](names, clip, prompt_len=P, adjustor_method="scale", class_specific=True)
+        _seed_context(model, names, cfg, P, seed=1)
+        out = model(images, labels)
+        out["loss"].backward()
+        grads = torch.stack([model.prompt_learner.context_bank[c].grad for c in names], 0)
+        arrays = dict(logits=out["logits"], loss=out["loss"], labels=labels,
+                      token_ids=torch.cat([table[f"a photo of a {c}"] for c in names], 0),
+                      context_grad_head=grads[:KEEP], context_grad_norms=grads.flatten(1).norm(dim=1),
+                      logit_scale_grad=model.logit_scale.grad)
+        if semantics == "intended":
+            # one batch pass over the raw prompts, as the collapsed path does: head-mean map, per-head rows, attribution
+            clip.reset()
+            cap = {}
+            last = clip.model.transformer.resblocks[-1].attn
+            h = last.register_forward_hook(lambda m, i, o: cap.update(probs=o[1].detach()))
+            with torch.no_grad():
+                clip.model.transformer(model.prompt_learner().detach())
+            h.remove()
+            amap = clip.get_attention_map()                       # [65, 93, 93]
+            arrays["attn_map_head"] = amap[:KEEP]                  # the first KEEP classes in full
+            arrays["attn_map_last_col"] = amap[:, :, -1]           # column T-1 of every class (what attribution reads)
+            arrays["attn_row_sums"] = amap.sum(-1)
+            arrays["probs_per_head_rows"] = cap["probs"][:4, :, :4, :]   # [4 classes, 8 heads, 4 rows, 93]
+            arrays["attribution"] = model.attribution_monitor(amap)
+        _save(f"fullmodel_{semantics}_vitb16_c65", seed_weights=2, seed_images=0, seed_context=1, batch=B, prompt_len=P,
+              class_names=np.array(names), **arrays)
+        print(f"  {semantics}: {time.time() - t0:.0f}s")
+
+
+def g_image_tower_l14(ref):
+    """BASELINE.json configs[4] image side: the full-depth (24-block) ViT-L/14@336 tower at batch 2, fp32 and with the
+    GEMM operands rounded to MXFP8 at the kernels' rounding points (regression pins of oracle/clip_ref.py: parity
+    unpinned against open_clip)."""
+    cfg = clip_ref.CONFIGS["ViT-L-14-336"]
+    sd = synth.make_state_dict(cfg, seed=2, text=False)
+    images = synth.make_images(2, cfg, 0)
+    with torch.no_grad():
+        t0 = time.time()
+        emb = clip_ref.encode_image(images, sd, cfg)
+        emb8 = clip_ref.encode_image(images, sd, cfg, emulate="mx8")
+    print(f"  {time.time() - t0:.0f}s")
+    _save("image_tower_ViT-L-14-336", seed_weights=2, seed_images=0, batch=2, embeddings=emb, embeddings_mx8=emb8)
+
+
+def g_fullmodel_l14(ref):
+    """BASELINE.json configs[4] text side + loss: the reference FullModel on ViT-L/14@336 dims (text d = 768, H = 12),
+    3 classes, 16 context tokens, batch 2, with the gradients its training loop uses (train.py:99-105)."""
+    cfg = clip_ref.CONFIGS["ViT-L-14-336"]
+    sd = synth.make_state_dict(cfg, seed=2)
+    names = class_list(3)
+    for semantics in ("literal", "intended"):
+        t0 = time.time()
+        arrays, model, clip = _full_model_case(ref, cfg, sd, names, 16, 2, semantics, seed_img=0)
+        arrays.pop("prompts")
+        arrays.pop("last_attention_capture")
+        _save(f"fullmodel_{semantics}_vitl14", seed_weights=2, seed_images=0, batch=2, prompt_len=16,
+              class_names=np.array(names), **arrays)
+        print(f"  {semantics}: {time.time() - t0:.0f}s")
+
+
+def g_checkpoint(ref):
+    """what `torch.save(model.state_dict())` of the reference holds (train.py:131-132) and what
+    test_cross_domain.py:43-61 loads back -- tensors of the reference FullModel's own state_dict() on the tiny config,
+    the legacy single-tensor context layout (`prompt_learner.context_emb`), and the logits that model produces.
+    RefClip is functional on the image side, so the `clip.model.visual.*` (and the unused text-side) entries an
+    open_clip module would contribute are added from the same seeded state dict under open_clip's key names."""
+    cfg = clip_ref.CONFIGS["tiny"]
+    sd = synth.make_state_dict(cfg, seed=2)
+    names = class_list(3)
+    arrays, model, clip = _full_model_case(ref, cfg, sd, names, 5, 4, "intended", seed_img=0, with_grads=False)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for k, v in sd.items():
+        state.setdefault("clip.model." + k, v)
+    legacy = {k: v for k, v in state.items() if "prompt_learner.context_bank" not in k}
+    legacy["prompt_learner.context_emb"] = torch.stack([state[f"prompt_learner.context_bank.{c}"] for c in names], 0)
+    out = {"logits": arrays["logits"], "token_ids": arrays["token_ids"], "class_names": np.array(names),
+           "keys": np.array(sorted(state.keys())), "legacy_keys": np.array(sorted(legacy.keys()))}
+    # tensors that are the seeded CLIP weights themselves are committed as (key, float64 sum) and regenerated from
+    # the seed by the test; everything else the reference's state_dict() holds is committed in full
+    seeded, sums = [], []
+    for k, v in state.items():
+        base = k[len("clip.model."):] if k.startswith("clip.model.") else None
+        if base in sd and torch.equal(v, sd[base]):
+            seeded.append(k)
+            sums.append(float(v.double().sum()))
+        else:
+            out["sd/" + k] = v
+    out["seeded_keys"], out["seeded_sums"] = np.array(seeded), np.array(sums)
+    out["legacy/prompt_learner.context_emb"] = legacy["prompt_learner.context_emb"]
+    _save("checkpoint_tiny", seed_weights=2, seed_images=0, batch=4, prompt_len=5, **out)
+
+
+def g_eval_metrics(ref):
+    """the reference's own utils/eval_metrics.py functions (:6-96) run on the reference FullModel
+    (tiny config) over a 3-batch loader, and on that model's attribution vectors."""
+    import contextlib
+    import io
+
+    em = ref["eval_metrics"]
+    cfg = clip_ref.CONFIGS["tiny"]
+    sd = synth.make_state_dict(cfg, seed=2)
+    names = class_list(6)
+    arrays, model, clip = _full_model_case(ref, cfg, sd, names, 5, 4, "intended", seed_img=0, with_grads=False)
+    model.eval()
+    images = synth.make_images(12, cfg, 41)
+    with torch.no_grad():
+        logits = model(images)["logits"]
+    # labels: the model's own prediction for two thirds of the samples, seeded random classes for the rest
+    pred = logits.argmax(1)
+    labels = pred.clone()
+    labels[::3] = synth.make_labels(12, len(names), seed=9)[::3]
+    top2 = logits.topk(2, dim=1).values
+    margin = float((top2[:, 0] - top2[:, 1]).min() / logits.abs().max())
+    loader = [(images[i:i + 4], labels[i:i + 4]) for i in range(0, 12, 4)]
+    with contextlib.redirect_stdout(io.StringIO()):
+        acc = em.evaluate_accuracy(model, loader, "cpu")
+        per = em.evaluate_per_class_accuracy(model, loader, "cpu", names)
+    clip.reset()
+    clip.model.transformer(model.prompt_learner().detach())
+    attr = model.attribution_monitor(clip.get_attention_map())     # [n_cls, P]
+    # the variance helper on fixed scores (this randomly initialised model's attribution is uniform to 1e-4, so its
+    # own variance would be a difference of round-off): 12 softmax rows in 3 label groups
+    scores = torch.softmax(synth.normal([12, 5], 10, "eval.scores"), dim=-1)
+    groups = synth.integers([12], 10, "eval.groups", 3)
+    _save("eval_metrics_tiny", seed_weights=2, seed_images=41, n_images=12, prompt_len=5, class_names=np.array(names),
+          token_ids=arrays["token_ids"], context=arrays["context"], labels=labels, logits=logits, min_top2_margin=margin,
+          accuracy=acc, per_class_names=np.array(list(per.keys())), per_class_acc=np.array(list(per.values())),
+          attribution=attr, attribution_entropy=em.attribution_entropy(attr), variance_scores=scores, variance_groups=groups,
+          attribution_variance=em.attribution_variance(scores, groups), scores_entropy=em.attribution_entropy(scores))
+    print(f"  accuracy {acc:.2f}  per-class {per}  min top-2 margin {margin:.3e}")
+
+
 ALL = {"attribution_monitor": g_attribution_monitor, "prompt_adjustor": g_prompt_adjustor,
        "fullmodel_tiny": g_fullmodel_tiny, "block_real_dims": g_block_real_dims, "image_tower": g_image_tower,
-       "fullmodel_b32": g_fullmodel_b32}
+       "fullmodel_b32": g_fullmodel_b32, "fullmodel_b16_c65": g_fullmodel_b16_c65, "image_tower_l14": g_image_tower_l14,
+       "fullmodel_l14": g_fullmodel_l14, "checkpoint": g_checkpoint, "eval_metrics": g_eval_metrics}
 
 
 def main():

@@ -138,7 +138,10 @@ def reference_modules():
     """Import the reference's L2/L3 modules from /root/reference with PromptLearner's
     device default patched to 'cpu' (prompt_learner.py:7 defaults to 'cuda' and FullModel never
     passes one, so construction would raise on a CPU-only box)."""
-    saved = {k: v for k, v in sys.modules.items() if k == "models" or k.startswith("models.")}
+    def ours(k):  # the reference's top-level package names (models/, utils/) may already be taken in this process
+        return k in ("models", "utils") or k.startswith("models.") or k.startswith("utils.")
+
+    saved = {k: v for k, v in sys.modules.items() if ours(k)}
     for k in saved:
         del sys.modules[k]
     sys.path.insert(0, REFERENCE_ROOT)
@@ -147,16 +150,18 @@ def reference_modules():
         import models.model_wrapper as mw
         import models.prompt_adjustor as pa
         import models.prompt_learner as pl
+        import utils.eval_metrics as em  # reference utils/eval_metrics.py:6-96 (torch only)
 
         old = pl.PromptLearner.__init__.__defaults__
         pl.PromptLearner.__init__.__defaults__ = old[:-1] + ("cpu",)
         try:
             yield {"FullModel": mw.FullModel, "PromptLearner": pl.PromptLearner,
-                   "AttributionMonitor": am.AttributionMonitor, "PromptAdjustor": pa.PromptAdjustor}
+                   "AttributionMonitor": am.AttributionMonitor, "PromptAdjustor": pa.PromptAdjustor,
+                   "eval_metrics": em}
         finally:
             pl.PromptLearner.__init__.__defaults__ = old
     finally:
         sys.path.remove(REFERENCE_ROOT)
-        for k in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+        for k in [k for k in sys.modules if ours(k)]:
             del sys.modules[k]
         sys.modules.update(saved)

@@ -249,14 +249,18 @@ __global__ __launch_bounds__(256 * POOL_KSPL) void pool_project_kernel(const flo
 // (no pos) and open_clip encode_text prologue (with pos).
 __global__ void embed_tokens_kernel(const float* __restrict__ table, int vocab, const float* __restrict__ pos,
                                     const int64_t* __restrict__ tokens, int64_t total, int L, int D, int add_pos,
-                                    float* out) {
+                                    float* out, int* bad) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int64_t t = i / D;
   const int c = (int)(i - t * D);
   int64_t id = tokens[t];
-  if (id < 0) id = 0;
-  if (id >= vocab) id = vocab - 1;
+  // an id outside the table is an error (torch's embedding raises): flagged for the host, which turns it into
+  // TAPCLIP_EINVAL; the lookup itself is clamped so that the kernel never reads out of bounds
+  if (id < 0 || id >= vocab) {
+    if (c == 0) atomicOr(bad, 1);
+    id = id < 0 ? 0 : vocab - 1;
+  }
   float v = table[id * D + c];
   if (add_pos) v += pos[(t % L) * D + c];
   out[i] = v;
@@ -416,9 +420,9 @@ hipError_t launch_add_delta(float* x, const bf16_t* dhi, const bf16_t* dlo, int6
 }
 
 hipError_t launch_embed_tokens(const float* table, int32_t vocab, const float* pos, const int64_t* tokens, int32_t n,
-                               int32_t L, int32_t D, int32_t add_pos, float* out, hipStream_t s) {
+                               int32_t L, int32_t D, int32_t add_pos, float* out, int* bad_flag, hipStream_t s) {
   const int64_t total = (int64_t)n * L * D;
-  hipLaunchKernelGGL(embed_tokens_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, table, vocab, pos, tokens, total, L, D, add_pos, out);
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, table, vocab, pos, tokens, total, L, D, add_pos, out, bad_flag);
   return hipGetLastError();
 }
 

@@ -163,7 +163,7 @@ hipError_t launch_pack_transpose(const float* src, int64_t N, int32_t K, int64_t
                                  bf16_t* lo, hipStream_t s);
 
 hipError_t launch_embed_tokens(const float* table, int32_t vocab, const float* pos, const int64_t* tokens,
-                               int32_t n, int32_t L, int32_t D, int32_t add_pos, float* out, hipStream_t s);
+                               int32_t n, int32_t L, int32_t D, int32_t add_pos, float* out, int* bad_flag, hipStream_t s);
 hipError_t launch_attribution(const float* amap, int32_t n, int32_t T, int32_t T2, int32_t P, int32_t normalize,
                               float* out, hipStream_t s);
 hipError_t launch_build_prompts(const float* ctx, const float* tok, const float* attr, int32_t attr_cols,

@@ -88,6 +88,7 @@ struct tapclip_tower {
         *lnpost_b = nullptr, *proj = nullptr;
   // text
   float *tok_emb = nullptr, *lnfin_g = nullptr, *lnfin_b = nullptr, *text_proj = nullptr;
+  int* bad_token = nullptr;   // device flag of tapclip_embed_tokens: set when a token id is outside the table
   float* split_ws = nullptr;  // scratch for the K-split tail tiles of gemm256.hip (64 MiB, handle-owned)
   // profiling
   bool prof_on = false;
@@ -826,8 +827,22 @@ int tapclip_embed_tokens(tapclip_tower_t* t, const int64_t* tokens, int32_t n_se
   if (t->cfg.kind != TAPCLIP_TOWER_TEXT) return fail(TAPCLIP_EINVAL, "needs a text tower");
   if (!t->tok_emb || !t->pos) return fail(TAPCLIP_ESTATE, "token_embedding / positional_embedding not loaded");
   if (add_pos && len > t->cfg.ctx_len) return fail(TAPCLIP_EINVAL, "len %d > ctx_len %d", len, t->cfg.ctx_len);
-  HIP_TRY(launch_embed_tokens(t->tok_emb, t->cfg.vocab, t->pos, tokens, n_seq, len, t->cfg.width, add_pos, out,
-                              static_cast<hipStream_t>(stream)));
+  if (n_seq <= 0 || len <= 0) return fail(TAPCLIP_EINVAL, "bad n_seq/len (%d, %d)", n_seq, len);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!t->bad_token) {
+    void* p = nullptr;
+    int rc = dev_alloc(t, sizeof(int), &p);
+    if (rc) return rc;
+    t->bad_token = static_cast<int*>(p);
+  }
+  HIP_TRY(hipMemsetAsync(t->bad_token, 0, sizeof(int), s));
+  HIP_TRY(launch_embed_tokens(t->tok_emb, t->cfg.vocab, t->pos, tokens, n_seq, len, t->cfg.width, add_pos, out, t->bad_token, s));
+  // this entry point is off the hot path (prompt construction, encode_text): it waits for the lookup so that an
+  // out-of-range id is reported like torch's embedding would (an error), not clamped silently
+  int bad = 0;
+  HIP_TRY(hipMemcpyAsync(&bad, t->bad_token, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (bad) return fail(TAPCLIP_EINVAL, "token id outside [0, %d) in tapclip_embed_tokens", t->cfg.vocab);
   return TAPCLIP_OK;
 }
 

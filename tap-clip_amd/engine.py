@@ -129,12 +129,13 @@ class TextTower(_Tower):
     kind = _lib.TOWER_TEXT
     _TOP = ("token_embedding.weight", "positional_embedding", "ln_final.weight", "ln_final.bias", "text_projection")
 
-    def __init__(self, cfg: ClipDims, state_dict, device="cuda", precision: str = "bf16", inference_only: bool = False):
-        # "fp8" is an image-tower precision (frozen weights, no backward: BASELINE.json configs[4]); the text
-        # tower carries the prompt gradients and stays bf16 beside it.  "fp16" (IEEE-half operands) likewise,
-        # unless the caller promises inference only: the gradients need bf16's exponent range, the forward does not.
-        if precision == "fp8" or (precision == "fp16" and not inference_only):
-            precision = "bf16"
+    def __init__(self, cfg: ClipDims, state_dict, device="cuda", precision: str = "bf16"):
+        # "fp8" and "fp16" are image-tower precisions (frozen weights, forward only).  The text tower carries the
+        # prompt gradients, which need bf16's exponent range: beside an fp8 image tower (a throughput mode) it runs
+        # plain bf16; beside the IEEE-half image tower (the mode that holds BASELINE.json's 1e-3 on embeddings AND
+        # logits) it runs split-bf16 (three MFMA products, ~2^-16 relative, forward and backward) -- it is a tenth
+        # of the image tower's work, and the IEEE-half text tower of round 1 left cfg-1 logits at 1.3e-3.
+        precision = {"fp8": "bf16", "fp16": "bf16x3"}.get(precision, precision)
         super().__init__(cfg, cfg.text, state_dict, device, precision)
 
     def _wanted(self, key):

@@ -10,8 +10,8 @@ under open_clip's names so `state_dict()` / `load_state_dict()` keep the referen
 
 Extra keyword-only knobs (defaults keep behaviour):
   precision       "bf16" (fast) | "bf16x3" (split-bf16, ~fp32 accuracy: the parity mode) |
-                  "fp16" (image tower on the IEEE-half build of the same kernels: bf16 speed, 2.8e-4 embedding
-                  error; text tower bf16) |
+                  "fp16" (the fast mode INSIDE BASELINE.json's 1e-3 bound: image tower on the IEEE-half build of the
+                  same kernels -- bf16 speed, 2.8e-4 embedding error -- text tower split-bf16) |
                   "fp8" (image tower block GEMMs on MXFP8 MFMA, text tower bf16; a throughput mode:
                   ~4 % error per GEMM)
   attn_semantics  "intended": the text hook yields the head-mean softmax map [n,T,T] that the
@@ -20,7 +20,11 @@ Extra keyword-only knobs (defaults keep behaviour):
                   nn.MultiheadAttention is the attention OUTPUT, so `.mean(dim=1)` gives [n,D]
                   (SURVEY.md section 0 item 1).
   state_dict      pass weights directly instead of `pretrained_path`.
-  bpe_path        CLIP's `bpe_simple_vocab_16e6.txt.gz` for the real tokenizer (default: hash stand-in).
+  bpe_path        CLIP's `bpe_simple_vocab_16e6.txt.gz` for the real tokenizer.  Default: $TAPCLIP_BPE_PATH, else the
+                  copy inside an installed `open_clip` package.  Real weights (`pretrained_path`) without any
+                  vocabulary raise -- the hash stand-in would feed them arbitrary token ids -- unless
+                  `tokenizer="hash"` asks for it.  Synthetic weights (`state_dict=`) default to the stand-in.
+  tokenizer       "bpe" | "hash" | a callable `text -> [n,77] int64`; None picks as described above.
 """
 from __future__ import annotations
 
@@ -85,7 +89,7 @@ class _TextTransformer(_Bag):
         attn_mod = self.resblocks[-1].attn
         user_hooks = len(attn_mod._forward_hooks) > 0
         intended = own.attn_semantics == "intended"
-        r = own._text_now().forward(x, causal=causal, want_hidden=True, want_heads=user_hooks and intended,
+        r = own._text.forward(x, causal=causal, want_hidden=True, want_heads=user_hooks and intended,
                               want_mean=intended, want_attn_out=not intended)
         if intended:
             own.attention_maps.append(r["attn_mean"])               # [n, T, T]
@@ -111,7 +115,7 @@ class _ClipModel(_Bag):
     def encode_text(self, text: torch.Tensor, normalize: bool = False) -> torch.Tensor:
         own = self._owner
         x = own._text.embed_tokens(text, add_pos=True)
-        hidden = own._text_now().forward(x, causal=True)["hidden"]
+        hidden = own._text.forward(x, causal=True)["hidden"]
         return own._text.pool_project(hidden, index=text.argmax(dim=-1), ln_final=True, normalize=normalize)
 
 
@@ -180,7 +184,7 @@ class CLIPWrapper(nn.Module):
     def __init__(self, model_name: str = "ViT-B-32", pretrained_path: Optional[str] = "path/to/open_clip_pytorch_model.bin",
                  device: str = "cuda", *, precision: str = "bf16", attn_semantics: str = "intended",
                  state_dict: Optional[Dict[str, torch.Tensor]] = None, config: Optional[ClipDims] = None,
-                 bpe_path: Optional[str] = None):
+                 bpe_path: Optional[str] = None, tokenizer=None):
         super().__init__()
         if attn_semantics not in ("intended", "literal"):
             raise ValueError(f"attn_semantics must be 'intended' or 'literal', got {attn_semantics!r}")
@@ -188,10 +192,12 @@ class CLIPWrapper(nn.Module):
         self.cfg = config or get_config(model_name)
         self.precision = precision
         self.attn_semantics = attn_semantics
+        real_weights = state_dict is None
         if state_dict is None:
             # a plain tensor state dict, as the reference loads (clip_wrapper.py:14); nothing is unpickled
             state_dict = torch.load(pretrained_path, map_location="cpu", weights_only=True)
         dev = torch.device(device)
+        tok = self._pick_tokenizer(tokenizer, bpe_path, real_weights)  # before any GPU work: it may refuse
 
         # frozen fp32 parameters under open_clip's names (state_dict compatibility)
         self.model = _ClipModel(self)
@@ -200,7 +206,6 @@ class CLIPWrapper(nn.Module):
         # the HIP towers (weights packed to bf16 hi/lo inside the handles); strict=True semantics
         self._vision = engine.VisionTower(self.cfg, state_dict, dev, precision)
         self._text = engine.TextTower(self.cfg, state_dict, dev, precision)
-        self._make_text_eval(state_dict, dev)
 
         # a later load_state_dict (reference test_cross_domain.py:61 loads `clip.model.*` back with
         # strict=False) must also reach the packed copies inside the HIP handles
@@ -210,13 +215,29 @@ class CLIPWrapper(nn.Module):
         self.register_load_state_dict_post_hook(CLIPWrapper._repack_after_load)
 
         self.attention_maps: List[torch.Tensor] = []
-        if bpe_path is not None:   # CLIP's real BPE vocabulary, when the user has the file
-            from ..tokenizer import BPETokenizer
-            self.tokenizer = BPETokenizer(bpe_path, self.cfg.ctx)
-        else:
-            self.tokenizer = HashTokenizer(self.cfg.vocab, self.cfg.ctx)
+        self.tokenizer = tok
         self.preprocess = _make_preprocess(self.cfg.image_size)
         self.eval()
+
+    def _pick_tokenizer(self, tokenizer, bpe_path, real_weights: bool):
+        """open_clip.get_tokenizer(model_name) in the reference (clip_wrapper.py:27).  Pretrained weights only mean
+        something with CLIP's own BPE ids, so they never get the hash stand-in silently."""
+        if callable(tokenizer):
+            return tokenizer
+        if tokenizer not in (None, "bpe", "hash"):
+            raise ValueError(f"tokenizer must be 'bpe', 'hash', a callable or None, got {tokenizer!r}")
+        if tokenizer != "hash":
+            from ..tokenizer import BPETokenizer, find_bpe_vocab
+            path = bpe_path or (find_bpe_vocab() if (real_weights or tokenizer == "bpe") else None)
+            if path is not None:
+                return BPETokenizer(path, self.cfg.ctx)
+            if real_weights or tokenizer == "bpe":
+                raise ValueError(
+                    "CLIPWrapper: pretrained weights need CLIP's BPE vocabulary (bpe_simple_vocab_16e6.txt.gz): pass "
+                    "bpe_path=..., set TAPCLIP_BPE_PATH, or install open_clip (its copy is picked up).  "
+                    "tokenizer='hash' selects the deterministic stand-in explicitly (token ids then have nothing to do "
+                    "with the ids the weights were trained on).")
+        return HashTokenizer(self.cfg.vocab, self.cfg.ctx)
 
     def _install(self, root: _Bag, sd: Dict[str, torch.Tensor], dev: torch.device) -> None:
         special = {"transformer": _TextTransformer, "token_embedding": _TokenEmbedding}
@@ -230,15 +251,6 @@ class CLIPWrapper(nn.Module):
                 node = node._modules[name]
             node.register_parameter(parts[-1], nn.Parameter(t.detach().to(dev, torch.float32), requires_grad=False))
 
-    def _make_text_eval(self, state_dict, dev) -> None:
-        """precision "fp16": forwards without autograd run on a second, IEEE-half text tower (logits inside the 1e-3
-        bound at full speed); anything that is differentiated keeps the bf16 tower (`_text`)."""
-        self._text_eval = (engine.TextTower(self.cfg, state_dict, dev, "fp16", inference_only=True)
-                           if self.precision == "fp16" else self._text)
-
-    def _text_now(self):
-        return self._text if torch.is_grad_enabled() else self._text_eval
-
     @staticmethod
     def _note_incoming_weights(module, state_dict, prefix, *args):
         module._reload_pending = any(k.startswith(prefix + "model.") for k in state_dict)
@@ -251,7 +263,6 @@ class CLIPWrapper(nn.Module):
             dev = torch.device(module.device)
             module._vision = engine.VisionTower(module.cfg, sd, dev, module.precision)
             module._text = engine.TextTower(module.cfg, sd, dev, module.precision)
-            module._make_text_eval(sd, dev)
             module.weights_version += 1
 
     # ---- reference surface -----------------------------------------------------------------

@@ -15,7 +15,9 @@ keys.  What changes is HOW the text side is evaluated:
   map vs the "literal" hook output, see clip_wrapper.py here).
 * multi-GPU: with `torch.distributed` initialised and `gather_images=True` every rank encodes its
   own image shard and the L2-normalised embeddings are all-gathered (RCCL over xGMI) before the
-  logits, so every rank returns logits for the GLOBAL batch (rank-major row order).
+  logits, so every rank returns logits for the GLOBAL batch (rank-major row order); labels passed to
+  `forward` are the rank's LOCAL labels and are gathered the same way, so loss and context gradients are
+  those of the global batch on every rank.
 """
 import math
 from typing import Optional
@@ -219,34 +221,52 @@ class FullModel(nn.Module):
         text_feat = _TextTowerFn.apply(adjusted, clip)
         with torch.no_grad():
             image_feat = self._image_features_end(image_feat, side)
-            if self.gather_images:
-                from ..dist import all_gather_rows
-                image_feat = all_gather_rows(image_feat)
+            image_feat, labels = self._gather(image_feat, labels)
         logits = _LogitsFn.apply(image_feat, text_feat, self.logit_scale)
         self.last_attribution = attribution
         outputs = {"logits": logits}
         if labels is not None:
-            loss_cls = F.cross_entropy(logits, labels.to(logits.device))
+            loss_cls = F.cross_entropy(logits, labels)
             outputs.update({"loss": loss_cls, "loss_cls": loss_cls})
         return outputs
 
+    def _gather(self, image_feat: torch.Tensor, labels):
+        """The one exchange step of the data-parallel path: every rank contributes its
+        [B_local, E] embeddings and its [B_local] labels, in the same rank-major order, so logits, loss and the
+        context gradients are those of the GLOBAL batch and identical on every rank (no gradient all-reduce)."""
+        if labels is not None:
+            labels = labels.to(image_feat.device)
+        if self.gather_images:
+            from ..dist import all_gather_rows
+            image_feat = all_gather_rows(image_feat)
+            if labels is not None:
+                labels = all_gather_rows(labels)
+        return image_feat, labels
+
     def forward(self, images, labels=None):
-        if torch.is_grad_enabled() and self.collapse_text and (
-                self.logit_scale.requires_grad or any(p.requires_grad for p in self.prompt_learner.parameters())):
+        wants_grad = torch.is_grad_enabled() and (
+            self.logit_scale.requires_grad or any(p.requires_grad for p in self.prompt_learner.parameters()))
+        if wants_grad and self.collapse_text:
             return self._forward_train(images, labels)
+        if wants_grad and labels is not None:
+            # the literal replay exists for parity checks only and runs without autograd: a loss from it could not
+            # be differentiated (the reference's own loop can, at n_cls * (B + 1) text passes per step)
+            raise RuntimeError("FullModel(collapse_text=False) has no backward: build the model with collapse_text=True "
+                               "to train, or call it under torch.no_grad() for the literal replay")
         with torch.no_grad():
             if not self.collapse_text:
+                if self.gather_images:
+                    raise RuntimeError("FullModel(collapse_text=False) is single-process (parity replay of the reference loop)")
                 logits = self._forward_literal(images)
+                labels = None if labels is None else labels.to(logits.device)
             else:
                 image_feat, side = self._image_features_begin(images)                     # model_wrapper.py:40-41
                 text_feat = self.text_features()
                 image_feat = self._image_features_end(image_feat, side)
-                if self.gather_images:
-                    from ..dist import all_gather_rows
-                    image_feat = all_gather_rows(image_feat)
+                image_feat, labels = self._gather(image_feat, labels)
                 logits = engine.logits(image_feat, text_feat, float(self.logit_scale.exp()))  # :79,83
             outputs = {"logits": logits}
             if labels is not None:
-                loss_cls = F.cross_entropy(logits, labels.to(logits.device))
+                loss_cls = F.cross_entropy(logits, labels)
                 outputs.update({"loss": loss_cls, "loss_cls": loss_cls})
         return outputs

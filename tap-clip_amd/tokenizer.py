@@ -2,11 +2,40 @@
 from its published description), for users who have the vocabulary file
 (`bpe_simple_vocab_16e6.txt.gz`, not available offline in this project: `CLIPWrapper` falls back to the
 deterministic `HashTokenizer` without it).  `tokenizer(texts) -> [n, 77] int64`, SOT/EOT added, zero
-padded, truncated with EOT kept -- what reference models/prompt_learner.py:31-33 consumes."""
+padded, truncated with EOT kept -- what reference models/prompt_learner.py:31-33 consumes.
+
+Parity unpinned (the vocabulary file is absent here, so no id sequence of open_clip's can be reproduced); known
+difference: open_clip first runs `ftfy.fix_text` on the input, which is skipped here (ftfy is not installed)."""
+
+
+def find_bpe_vocab():
+    """Path of CLIP's vocabulary file if the user's environment has one: $TAPCLIP_BPE_PATH, or the data file inside
+    an installed `open_clip` package (located through importlib, without importing the package).  None otherwise."""
+    import importlib.util
+    import os
+
+    env = os.environ.get("TAPCLIP_BPE_PATH")
+    if env:
+        return env
+    try:
+        spec = importlib.util.find_spec("open_clip")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.submodule_search_locations:
+        for d in spec.submodule_search_locations:
+            cand = os.path.join(d, "bpe_simple_vocab_16e6.txt.gz")
+            if os.path.exists(cand):
+                return cand
+    return None
 import gzip
 import html
 import re
 from functools import lru_cache
+
+try:  # CLIP's pattern uses the Unicode classes \p{L} / \p{N}, which only the third-party `regex` module has
+    import regex as _re_u
+except ImportError:  # pragma: no cover - ASCII classes: identical on ASCII text, differs on other scripts
+    _re_u = None
 from typing import Dict, List, Tuple, Union
 
 import torch
@@ -45,7 +74,11 @@ class BPETokenizer:
         self.context_length = context_length
         self.sot, self.eot = self.encoder["<start_of_text>"], self.encoder["<end_of_text>"]
         self.cache: Dict[str, str] = {}
-        self.pat = re.compile(r"<start_of_text>|<end_of_text>|'s|'t|'re|'ve|'m|'ll|'d|[a-zA-Z]+|[0-9]|[^\sa-zA-Z0-9]+")
+        if _re_u is not None:
+            self.pat = _re_u.compile(r"<start_of_text>|<end_of_text>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+",
+                                     _re_u.IGNORECASE)
+        else:
+            self.pat = re.compile(r"<start_of_text>|<end_of_text>|'s|'t|'re|'ve|'m|'ll|'d|[a-zA-Z]+|[0-9]|[^\sa-zA-Z0-9]+")
 
     def _bpe(self, token: str) -> str:
         if token in self.cache:
@@ -73,7 +106,7 @@ class BPETokenizer:
 
     def encode(self, text: str) -> List[int]:
         ids: List[int] = []
-        for tok in re.findall(self.pat, _clean(text)):
+        for tok in self.pat.findall(_clean(text)):
             tok = "".join(self.byte_encoder[b] for b in tok.encode("utf-8"))
             ids.extend(self.encoder[t] for t in self._bpe(tok).split(" "))
         return ids

@@ -18,7 +18,11 @@ def _count(model, dataloader, device):
         images, labels = images.to(device), labels.to(device)
         logits = model(images)["logits"]
         n_cls = logits.shape[1]
-        # under gather_images every rank holds the global logits; labels must then be global too
+        if getattr(model, "gather_images", False):
+            # data-parallel FullModel: every rank holds the GLOBAL logits (rank-major rows), so the rank's labels are
+            # gathered the same way and every rank counts the same global totals
+            from ..dist import all_gather_rows
+            labels = all_gather_rows(labels)
         preds = torch.argmax(logits, dim=1)
         hit = (preds == labels).to(torch.int64)
         size = max(n_cls, int(labels.max()) + 1) if correct is None else max(n_cls, correct.numel(), int(labels.max()) + 1)

@@ -1,0 +1,391 @@
+"""GPU parity at the BASELINE.json configurations that round 1 left without a test, against goldens produced by the
+REFERENCE's own classes (oracle/make_golden.py):
+
+  configs[2]  ViT-B/16 image + text towers, 65 classes, 16 context tokens (T = 93), attention-map write-back on:
+              the reference FullModel's logits / loss / gradients, the [65, 93, 93] head-mean map, per-head rows and
+              the attribution -- at the reference's batch 4 -- plus the batch-256 run through size-independent properties.
+  configs[4]  ViT-L/14@336: the full-depth (24-block) image tower in every precision incl. fp8 (MXFP8 GEMMs), the
+              d = 768 / H = 12 text tower forward and backward, and the reference FullModel with the gradients of its
+              training loop (train.py:99-105).
+  SURVEY 8f   rows 2 and 4: a state dict as the reference's FullModel produces it (train.py:131-132) loaded the way
+              test_cross_domain.py:43-61 does; the reference's utils/eval_metrics.py results on fixed inputs.
+  N > 1       one AdamW step on two ranks == the same step in one process on the global batch.
+
+Tolerances as in test_gpu_parity.py: TOL = 1e-3 for the modes that claim BASELINE.json's bound (bf16x3, and fp16 =
+IEEE-half image tower + split-bf16 text tower), TOL_BF16 = 2e-2 for plain bf16 (reported, not the parity claim)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import tap_clip_amd  # noqa: F401
+from conftest import golden, rel_l2, rel_max
+from oracle import clip_ref
+from tap_clip_amd import configs, synth
+from test_gpu_parity import DEV, TOL, TOL_BF16, _build_full, _report
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from tap_clip_amd import engine
+
+    return engine
+
+
+# ---- BASELINE configs[2] -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("semantics", ["literal", "intended"])
+def test_fullmodel_vitb16_65_classes_vs_reference(semantics):
+    g = golden(f"fullmodel_{semantics}_vitb16_c65")
+    ref = torch.from_numpy(g["logits"])
+    labels = torch.from_numpy(g["labels"]).to(DEV)
+    for precision, tol in (("bf16x3", TOL), ("fp16", TOL), ("bf16", TOL_BF16)):
+        model, images = _build_full("ViT-B-16", g, semantics, precision)
+        with torch.no_grad():
+            out = model(images, labels)
+        _report(f"FullModel ViT-B/16 65 classes {semantics} {precision} logits", out["logits"], ref)
+        assert out["logits"].shape == (4, 65)
+        assert rel_max(out["logits"].cpu(), ref) < tol
+        assert abs(float(out["loss"]) - float(g["loss"])) < tol * max(1.0, abs(float(g["loss"])))
+        if semantics == "intended":
+            amap = model.clip.attention_maps[0].cpu()                        # pass 1's capture: [65, 93, 93]
+            assert amap.shape == (65, 93, 93)
+            _report(f"  head-mean map {precision}", amap[:8], torch.from_numpy(g["attn_map_head"]))
+            assert rel_max(amap[:8], torch.from_numpy(g["attn_map_head"])) < tol
+            assert rel_max(amap[:, :, -1], torch.from_numpy(g["attn_map_last_col"])) < tol
+            assert torch.allclose(amap.sum(-1), torch.from_numpy(g["attn_row_sums"]), atol=1e-4)
+            assert rel_max(model.last_attribution.cpu(), torch.from_numpy(g["attribution"])) < tol
+        if precision == "bf16x3":
+            # the training step of the same model: context gradients of the reference's autograd
+            model.train()
+            o = model(images, labels)
+            o["loss"].backward()
+            names = g["class_names"].tolist()
+            grad = torch.stack([model.prompt_learner.context_bank[c].grad for c in names], 0).cpu()
+            _report(f"  context grad {precision}", grad[:8], torch.from_numpy(g["context_grad_head"]))
+            assert rel_max(grad[:8], torch.from_numpy(g["context_grad_head"])) < tol
+            assert rel_max(grad.flatten(1).norm(dim=1), torch.from_numpy(g["context_grad_norms"])) < tol
+            assert abs(float(model.logit_scale.grad) - float(g["logit_scale_grad"])) < tol * max(1.0, abs(float(g["logit_scale_grad"])))
+        del model
+        torch.cuda.empty_cache()
+
+
+def test_per_head_write_back_vitb16_65_classes(eng):
+    """The per-head probabilities [n, 8, 93, 93] that a hook on resblocks[-1].attn receives (reference
+    clip_wrapper.py:29-40, intended semantics) against the reference run's own rows."""
+    g = golden("fullmodel_intended_vitb16_c65")
+    model, _ = _build_full("ViT-B-16", g, "intended", "bf16x3")
+    got = {}
+    model.clip.model.transformer.resblocks[-1].attn.register_forward_hook(lambda m, i, o: got.update(p=o[0]))
+    with torch.no_grad():
+        model.clip.reset()
+        model.clip.model.transformer(model.prompt_learner().detach())
+    p = got["p"].cpu()
+    assert p.shape == (65, 8, 93, 93)
+    assert rel_max(p[:4, :, :4, :], torch.from_numpy(g["probs_per_head_rows"])) < TOL
+    assert torch.allclose(p.sum(-1), torch.ones(65, 8, 93), atol=1e-5)
+
+
+def test_fullmodel_vitb16_65_classes_batch_256_properties():
+    """configs[2] at its full size (batch 256): finite, run-to-run bit-identical, and the rows of the 4 golden images
+    inside the big batch equal the batch-4 rows (text features do not depend on the images)."""
+    g = golden("fullmodel_intended_vitb16_c65")
+    model, images4 = _build_full("ViT-B-16", g, "intended", "bf16")
+    cfg = configs.get_config("ViT-B-16")
+    big = torch.cat([images4, synth.make_images(252, cfg, 77).to(DEV)], 0)
+    with torch.no_grad():
+        a = model(big)["logits"]
+        b = model(big)["logits"]
+        small = model(images4)["logits"]
+    assert a.shape == (256, 65) and bool(torch.isfinite(a).all())
+    assert torch.equal(a, b)
+    assert torch.equal(a[:4], small)
+    assert rel_max(a[:4].cpu(), torch.from_numpy(g["logits"])) < TOL_BF16
+    assert model.clip.attention_maps[0].shape == (65, 93, 93)
+
+
+# ---- BASELINE configs[4] -------------------------------------------------------------------------------------
+def test_encode_image_vit_l14_336_full_depth(eng):
+    """All 24 blocks of ViT-L/14@336 (577 tokens: the flash-style attention kernel; K = 1024 / 4096 GEMMs) at batch 2
+    against the fp32 oracle's embeddings, in every precision; fp8 also against the oracle with MXFP8 operand rounding."""
+    g = golden("image_tower_ViT-L-14-336")
+    cfg = configs.get_config("ViT-L-14-336")
+    sd = synth.make_state_dict(cfg, seed=int(g["seed_weights"]), text=False)
+    images = synth.make_images(int(g["batch"]), cfg, int(g["seed_images"])).to(DEV)
+    ref, ref8 = torch.from_numpy(g["embeddings"]), torch.from_numpy(g["embeddings_mx8"])
+    for precision, tol in (("bf16x3", TOL), ("fp16", TOL), ("bf16", TOL_BF16)):
+        tower = eng.VisionTower(cfg, sd, DEV, precision)
+        emb = tower.encode_image(images).cpu()
+        _report(f"encode_image ViT-L/14@336 24 blocks {precision}", emb, ref)
+        assert rel_l2(emb, ref) < tol and rel_max(emb, ref) < (tol if precision != "bf16" else 2 * TOL_BF16)
+        tower.close()
+        del tower
+        torch.cuda.empty_cache()
+    tower = eng.VisionTower(cfg, sd, DEV, "fp8")
+    emb = tower.encode_image(images).cpu()
+    cos = torch.nn.functional.cosine_similarity(emb, ref, dim=-1)
+    _report("encode_image ViT-L/14@336 24 blocks fp8 vs fp32", emb, ref)
+    _report("encode_image ViT-L/14@336 24 blocks fp8 vs MXFP8-rounding oracle", emb, ref8)
+    # a throughput mode (3 mantissa bits per operand element), parity unpinned against the reference: bounded, not claimed
+    assert rel_l2(emb, ref) < 0.2 and float(cos.min()) > 0.98
+    assert rel_l2(emb, ref8) < 0.2
+    assert torch.equal(emb, tower.encode_image(images).cpu())
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_text_tower_l14_dims_forward_backward_vs_oracle(eng, precision):
+    """The ViT-L/14 text tower (d = 768, 12 heads, mlp 3072, 12 blocks) at T = 16 + 77 = 93: hidden states against
+    `clip_ref.text_transformer_raw`, dL/dx against torch autograd through the oracle."""
+    cfg = configs.get_config("ViT-L-14-336")
+    ocfg = clip_ref.CONFIGS["ViT-L-14-336"]
+    sd = synth.make_state_dict(cfg, seed=2, vision=False)
+    tower = eng.TextTower(cfg, sd, DEV, precision)
+    n, T, D = 5, 93, 768
+    x = torch.cat([synth.normal([n, 16, D], 4, "l14.ctx"), synth.normal([n, 77, D], 4, "l14.tok", 0.02)], dim=1)
+    gfeat = synth.normal([n, cfg.embed_dim], 4, "l14.g")
+    xr = x.clone().requires_grad_(True)
+    hidden, probs, _ = clip_ref.text_transformer_raw(xr, sd, ocfg, want_probs=True)
+    feat = hidden[:, -1, :] @ sd["text_projection"]
+    feat = feat / feat.norm(dim=-1, keepdim=True)
+    (feat * gfeat).sum().backward()
+    tol = TOL if precision == "bf16x3" else 5e-2
+    r = tower.forward(x.to(DEV), want_heads=True, want_mean=True)
+    _report(f"L/14 text tower {precision} hidden", r["hidden"], hidden.detach())
+    assert rel_max(r["hidden"].cpu(), hidden.detach()) < (TOL if precision == "bf16x3" else TOL_BF16)
+    assert rel_max(r["attn_heads"].cpu(), probs.detach()) < (TOL if precision == "bf16x3" else TOL_BF16)
+    assert rel_max(r["attn_mean"].cpu(), probs.detach().mean(1)) < (TOL if precision == "bf16x3" else TOL_BF16)
+    got = tower.pool_project(r["hidden"], normalize=True)
+    assert rel_max(got.cpu(), feat.detach()) < (TOL if precision == "bf16x3" else TOL_BF16)
+    g_hidden = tower.pool_project_backward(r["hidden"], gfeat.to(DEV), normalize=True)
+    gx = tower.backward(x.to(DEV), g_hidden).cpu()
+    _report(f"L/14 text tower {precision} dL/dx", gx, xr.grad)
+    assert rel_l2(gx, xr.grad) < tol
+    assert rel_max(gx[:, :16], xr.grad[:, :16]) < tol
+
+
+@pytest.mark.parametrize("semantics", ["literal", "intended"])
+def test_fullmodel_vitl14_vs_reference(semantics):
+    """The reference FullModel on ViT-L/14@336 (image tower 24 blocks, text d = 768): logits, loss and the gradients
+    its training loop uses, bf16x3 at 1e-3; the fp8 image tower of configs[4] beside it, bounded."""
+    g = golden(f"fullmodel_{semantics}_vitl14")
+    ref = torch.from_numpy(g["logits"])
+    labels = torch.from_numpy(g["labels"]).to(DEV)
+    names = g["class_names"].tolist()
+    model, images = _build_full("ViT-L-14-336", g, semantics, "bf16x3")
+    model.train()
+    out = model(images, labels)
+    _report(f"FullModel ViT-L/14@336 {semantics} bf16x3 logits", out["logits"], ref)
+    assert rel_max(out["logits"].detach().cpu(), ref) < TOL
+    assert abs(float(out["loss"]) - float(g["loss"])) < TOL * max(1.0, abs(float(g["loss"])))
+    out["loss"].backward()
+    grad = torch.stack([model.prompt_learner.context_bank[c].grad for c in names], 0).cpu()
+    gref = torch.from_numpy(g["context_grad"])
+    _report(f"FullModel ViT-L/14@336 {semantics} bf16x3 context grad", grad, gref)
+    assert rel_max(grad, gref) < TOL and rel_l2(grad, gref) < TOL
+    assert abs(float(model.logit_scale.grad) - float(g["logit_scale_grad"])) < TOL * max(1.0, abs(float(g["logit_scale_grad"])))
+    del model
+    torch.cuda.empty_cache()
+    model, images = _build_full("ViT-L-14-336", g, semantics, "fp8")  # configs[4]: fp8 image tower, bf16 text tower
+    with torch.no_grad():
+        lg = model(images)["logits"].cpu()
+    _report(f"FullModel ViT-L/14@336 {semantics} fp8 logits", lg, ref)
+    assert rel_max(lg, ref) < 0.3 and bool(torch.isfinite(lg).all())
+
+
+# ---- real-dims encode_text (causal mask, positional embedding, ln_final, EOT pool) -----------------------
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_encode_text_vitb16_dims(eng, precision):
+    from tap_clip_amd.models import CLIPWrapper
+
+    cfg = configs.get_config("ViT-B-16")
+    sd = synth.make_state_dict(cfg, seed=2)
+    clip = CLIPWrapper("ViT-B-16", None, DEV, precision=precision, state_dict=sd)
+    tokens = torch.zeros(6, cfg.ctx, dtype=torch.long)
+    for i in range(6):
+        L = 3 + 11 * i
+        tokens[i, 0] = cfg.vocab - 2
+        tokens[i, 1:1 + L] = synth.integers([L], 3, f"t16.{i}", cfg.vocab - 3) + 1
+        tokens[i, 1 + L] = cfg.vocab - 1          # EOT = the largest id: argmax finds it (open_clip's pooling)
+    out = clip.encode_text(tokens.to(DEV))
+    with torch.no_grad():
+        ref = clip_ref.encode_text(tokens, sd, clip_ref.CONFIGS["ViT-B-16"])
+    _report(f"encode_text ViT-B/16 dims {precision}", out, ref)
+    assert out.shape == (6, 512)
+    assert rel_max(out.cpu(), ref) < (TOL if precision == "bf16x3" else TOL_BF16)
+
+
+# ---- a reference-produced state dict ---------------------------------------------------------------
+def _reference_state_dict(g):
+    """The reference FullModel's state_dict() of oracle/make_golden.py g_checkpoint: seeded CLIP tensors regenerated
+    (and checked against their committed sums), everything else from the fixture."""
+    cfg = configs.get_config("tiny")
+    sd = synth.make_state_dict(cfg, seed=int(g["seed_weights"]))
+    state = {}
+    for k, want in zip(g["seeded_keys"].tolist(), g["seeded_sums"].tolist()):
+        t = sd[k[len("clip.model."):]]
+        assert abs(float(t.double().sum()) - want) <= 1e-9 * max(1.0, abs(want)), k
+        state[k] = t
+    for f in g.files:
+        if f.startswith("sd/"):
+            state[f[3:]] = torch.from_numpy(g[f])
+    assert sorted(state) == g["keys"].tolist()
+    return state
+
+
+@pytest.mark.parametrize("legacy", [False, True])
+def test_checkpoint_from_the_reference_loads(legacy):
+    """reference test_cross_domain.py:43-67 against a state dict the REFERENCE's FullModel produced: filter / convert
+    as the script does, load with strict=False into a model built from other weights and another context draw, get
+    the reference's logits; then register an unseen class."""
+    from tap_clip_amd.models import CLIPWrapper, FullModel
+
+    g = golden("checkpoint_tiny")
+    names = g["class_names"].tolist()
+    state_dict = _reference_state_dict(g)
+    if legacy:  # the older layout the script still converts: one [n_cls, P, D] tensor
+        state_dict = {k: v for k, v in state_dict.items() if "prompt_learner.context_bank" not in k}
+        state_dict["prompt_learner.context_emb"] = torch.from_numpy(g["legacy/prompt_learner.context_emb"])
+        assert sorted(state_dict) == g["legacy_keys"].tolist()
+    cfg = configs.get_config("tiny")
+    torch.manual_seed(99)
+    clip = CLIPWrapper("tiny", None, DEV, precision="bf16x3", state_dict=synth.make_state_dict(cfg, seed=3))
+    table = {f"a photo of a {c}": torch.from_numpy(g["token_ids"][i:i + 1]) for i, c in enumerate(names)}
+    table["a photo of a Bike"] = torch.from_numpy(g["token_ids"][0:1])
+    clip.tokenizer = lambda text: table[text].clone()
+    model = FullModel(names, clip, prompt_len=int(g["prompt_len"]), adjustor_method="scale", class_specific=True)
+    images = synth.make_images(int(g["batch"]), cfg, int(g["seed_images"])).to(DEV)
+    ref = torch.from_numpy(g["logits"])
+    with torch.no_grad():
+        assert rel_max(model.eval()(images)["logits"].cpu(), ref) > 1e-2   # other weights, other answer
+    # --- the script's conversion, verbatim in structure (test_cross_domain.py:43-61)
+    converted = {}
+    if "prompt_learner.context_emb" in state_dict:
+        old_ctx = state_dict["prompt_learner.context_emb"]
+        for i, cls_name in enumerate(names):
+            converted[f"prompt_learner.context_bank.{cls_name}"] = old_ctx[i]
+    for k, v in state_dict.items():
+        if "prompt_learner" not in k:
+            converted[k] = v
+    if not legacy:  # test_cross_domain2.py:81 loads the dict as saved
+        converted = state_dict
+    missing, unexpected = model.load_state_dict(converted, strict=False)
+    assert not unexpected, unexpected
+    model.eval()
+    with torch.no_grad():
+        got = model(images)["logits"].cpu()
+    _report(f"logits after loading the reference's state dict (legacy={legacy})", got, ref)
+    assert rel_max(got, ref) < TOL
+    model.prompt_learner.add_class_prompt("Bike")
+    with torch.no_grad():
+        assert model(images)["logits"].shape == (4, len(names) + 1)
+
+
+# ---- the reference's eval_metrics results ----------------------------------------------------------
+def test_eval_metrics_vs_reference():
+    from tap_clip_amd.models import CLIPWrapper, FullModel
+    from tap_clip_amd.utils import eval_metrics
+
+    g = golden("eval_metrics_tiny")
+    names = g["class_names"].tolist()
+    cfg = configs.get_config("tiny")
+    clip = CLIPWrapper("tiny", None, DEV, precision="bf16x3", state_dict=synth.make_state_dict(cfg, seed=int(g["seed_weights"])))
+    table = {f"a photo of a {c}": torch.from_numpy(g["token_ids"][i:i + 1]) for i, c in enumerate(names)}
+    clip.tokenizer = lambda text: table[text].clone()
+    model = FullModel(names, clip, prompt_len=int(g["prompt_len"]), adjustor_method="scale", class_specific=True)
+    with torch.no_grad():
+        for i, c in enumerate(names):
+            model.prompt_learner.context_bank[c].copy_(torch.from_numpy(g["context"][i]))
+    images = synth.make_images(int(g["n_images"]), cfg, int(g["seed_images"]))
+    labels = torch.from_numpy(g["labels"])
+    loader = [(images[i:i + 4], labels[i:i + 4]) for i in range(0, 12, 4)]
+    with torch.no_grad():
+        logits = model.eval()(images.to(DEV))["logits"].cpu()
+    assert rel_max(logits, torch.from_numpy(g["logits"])) < TOL
+    assert float(g["min_top2_margin"]) > 100 * TOL     # no prediction of the fixture is a near-tie
+    assert eval_metrics.evaluate_accuracy(model, loader, DEV) == pytest.approx(float(g["accuracy"]), abs=1e-9)
+    per = eval_metrics.evaluate_per_class_accuracy(model, loader, DEV, names)
+    assert list(per.keys()) == g["per_class_names"].tolist()
+    assert list(per.values()) == pytest.approx(g["per_class_acc"].tolist(), abs=1e-9)
+    attr = model.last_attribution.cpu()                 # the HIP path's attribution of the same prompts
+    assert rel_max(attr, torch.from_numpy(g["attribution"])) < TOL
+    assert eval_metrics.attribution_entropy(attr) == pytest.approx(float(g["attribution_entropy"]), rel=1e-4)
+    scores, groups = torch.from_numpy(g["variance_scores"]), torch.from_numpy(g["variance_groups"])
+    assert eval_metrics.attribution_variance(scores, groups) == pytest.approx(float(g["attribution_variance"]), rel=1e-5)
+    assert eval_metrics.attribution_entropy(scores) == pytest.approx(float(g["scores_entropy"]), rel=1e-5)
+
+
+# ---- N > 1 training: two ranks (sharing the one GPU of the test box, gloo transport) -------------------------------
+_TRAIN_RANKS = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import tap_clip_amd
+from tap_clip_amd import configs, synth
+from tap_clip_amd.dist import shard_rows
+from tap_clip_amd.models import CLIPWrapper, FullModel
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+cfg = configs.get_config("tiny")
+sd = synth.make_state_dict(cfg, seed=2)
+names = ["Backpack", "Laptop", "Mug"]
+def build(gather):
+    torch.manual_seed(7)   # same context draw on every rank
+    clip = CLIPWrapper("tiny", None, "cuda:0", precision="bf16x3", state_dict=sd)
+    return FullModel(names, clip, prompt_len=5, class_specific=True, gather_images=gather)
+images, labels = synth.make_images(8, cfg, 0), synth.make_labels(8, 3)
+lo, hi = shard_rows(8, rank, world)
+def one_step(model, x, y):
+    opt = torch.optim.AdamW(model.prompt_learner.parameters(), lr=2e-3, weight_decay=0.01)   # reference train.py:65-67
+    model.train()
+    out = model(x.cuda(), y.cuda())                                                            # train.py:99
+    opt.zero_grad(); out["loss"].backward(); opt.step()                                        # train.py:103-105
+    grads = torch.stack([model.prompt_learner.context_bank[c].grad for c in names]).cpu()
+    ctx = torch.stack([model.prompt_learner.context_bank[c].detach() for c in names]).cpu()
+    return out["logits"].detach().cpu(), float(out["loss"]), grads, ctx
+lg_s, loss_s, g_s, ctx_s = one_step(build(True), images[lo:hi], labels[lo:hi])    # sharded: local images, local labels
+lg_f, loss_f, g_f, ctx_f = one_step(build(False), images, labels)                 # one process, global batch
+assert lg_s.shape == (8, 3)
+rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+assert rel(lg_s, lg_f) < 1e-5 and abs(loss_s - loss_f) < 1e-5 * max(1.0, abs(loss_f)), (rel(lg_s, lg_f), loss_s, loss_f)
+assert rel(g_s, g_f) < 1e-4, rel(g_s, g_f)
+assert float((ctx_s - ctx_f).abs().max()) < 1e-5, float((ctx_s - ctx_f).abs().max())
+# every rank holds the same updated context (no gradient all-reduce is needed: the loss is the global one everywhere)
+parts = [torch.empty_like(ctx_s) for _ in range(world)]
+dist.all_gather(parts, ctx_s)
+assert all(torch.equal(p, parts[0]) for p in parts)
+# the evaluation helpers count global totals on every rank
+from tap_clip_amd.utils import eval_metrics
+import contextlib, io
+m = build(True).eval()
+with contextlib.redirect_stdout(io.StringIO()):
+    acc_s = eval_metrics.evaluate_accuracy(m, [(images[lo:hi], labels[lo:hi])], "cuda:0")
+    acc_f = eval_metrics.evaluate_accuracy(build(False).eval(), [(images, labels)], "cuda:0")
+assert acc_s == acc_f, (acc_s, acc_f)
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok", rel(g_s, g_f))
+"""
+
+
+def test_two_ranks_sharded_train_step_equals_single(tmp_path):
+    script = tmp_path / "train_ranks.py"
+    script.write_text(_TRAIN_RANKS % ROOT)
+    port = 29900 + os.getpid() % 90
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.count("ok") == 2, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_literal_replay_refuses_to_train():
+    g = golden("fullmodel_intended_tiny")
+    model, images = _build_full("tiny", g, "intended", "bf16", collapse=False)
+    model.train()
+    with pytest.raises(RuntimeError, match="no backward"):
+        model(images, torch.from_numpy(g["labels"]).to(DEV))
+    with torch.no_grad():
+        assert model(images)["logits"].shape == (4, 3)

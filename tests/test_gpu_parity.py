@@ -131,11 +131,15 @@ def test_block_vs_golden(eng, tag, precision):
         assert rel_max(got.cpu(), ref) < tol, name
     assert rel_max(r["attn_heads"][:, 0, :8, :].cpu(), torch.from_numpy(g["probs_head0_rows"])) < tol
     assert torch.allclose(r["attn_heads"].sum(-1).cpu(), torch.ones(n, heads, T), atol=1e-5)
-    if precision == "bf16":  # same rounding points as the kernels -> accumulation-order noise only
+    if precision == "bf16":  # same rounding points AND the same fitted GELU as the kernels -> accumulation-order noise only
         taps = {}
         y, _ = clip_ref.block_forward(x, sd, "transformer.resblocks.0.", heads, emulate="bf16", taps=taps)
         _report(f"block {tag} bf16 vs emulated", r["hidden"], y)
-        assert rel_l2(r["hidden"].cpu(), y) < TOL_EMU
+        _report(f"block {tag} bf16 attn_out vs emulated", r["attn_out"], taps["attn_out"])
+        # round 1 measured 1.2e-3 rel-L2 / 3.0e-3 rel-max here against an emulation with the EXACT-erf GELU: the kernels'
+        # fitted GELU (2.5e-5 absolute, common.h) is 1-6 % of a bf16 ulp of the MLP hidden values, so a few per cent of
+        # them rounded the other way.  With the fit restated in the oracle (clip_ref.gelu_fit) both bounds hold again.
+        assert rel_l2(r["hidden"].cpu(), y) < TOL and rel_max(r["hidden"].cpu(), y) < TOL_EMU
 
 
 def test_block_small_gemm_split_k(eng):
@@ -334,9 +338,12 @@ def _build_full(cfg_name, g, semantics, precision, collapse=True):
     clip.tokenizer = lambda text: table[text].clone()
     model = FullModel(names, clip, prompt_len=int(g["prompt_len"]), adjustor_method="scale", class_specific=True,
                       collapse_text=collapse)
+    # the context tokens: committed for the small cases, a seed of the build's own generator for the large ones
+    ctx = (torch.from_numpy(g["context"]) if "context" in g.files else
+           synth.make_prompts(len(names), int(g["prompt_len"]), cfg, seed=int(g["seed_context"]))[0])
     with torch.no_grad():
         for i, c in enumerate(names):
-            model.prompt_learner.context_bank[c].copy_(torch.from_numpy(g["context"][i]))
+            model.prompt_learner.context_bank[c].copy_(ctx[i])
     images = synth.make_images(int(g["batch"]), cfg, int(g["seed_images"]))
     return model.eval(), images.to(DEV)
 
@@ -450,9 +457,9 @@ def test_fullmodel_vitb32_cfg1_vs_reference(semantics):
     """BASELINE.json configs[0]: ViT-B/32, batch 8, 10 classes, P=5 -- the reference FullModel's own logits."""
     g = golden(f"fullmodel_{semantics}_vitb32")
     ref = torch.from_numpy(g["logits"])
-    # fp16: both towers on the IEEE-half build for this no-grad forward: 9.8e-4 rel-L2 / 1.3e-3 rel-max on these
-    # small-magnitude logits (bf16: 1.4e-2 / 2.0e-2), bound 2e-3; the embeddings themselves are at 2.8e-4
-    for precision, tol in (("bf16x3", TOL), ("bf16", TOL_BF16), ("fp16", 2 * TOL)):
+    # fp16 = IEEE-half image tower (2.8e-4 on the embeddings) + split-bf16 text tower: the fast mode inside the 1e-3
+    # bound, on logits too (round 1's IEEE-half text tower left these small-magnitude logits at 1.3e-3 rel-max)
+    for precision, tol in (("bf16x3", TOL), ("bf16", TOL_BF16), ("fp16", TOL)):
         model, images = _build_full("ViT-B-32", g, semantics, precision)
         with torch.no_grad():
             out = model(images, torch.from_numpy(g["labels"]).to(DEV))
@@ -534,6 +541,16 @@ def test_errors(eng):
         eng.VisionTower(cfg, bad, DEV, "bf16")
     with pytest.raises(RuntimeError, match="no CPU path"):
         eng.VisionTower(cfg, sd, "cpu", "bf16")
+    # a token id outside the embedding table is an error, as in torch (not a silent clamp)
+    text = eng.TextTower(cfg, sd, DEV, "bf16")
+    ok = torch.zeros(2, 7, dtype=torch.long)
+    assert text.embed_tokens(ok, add_pos=False).shape == (2, 7, cfg.text.width)
+    for bad_id in (cfg.vocab, -1):
+        ids = ok.clone()
+        ids[1, 3] = bad_id
+        with pytest.raises(ValueError, match="token id"):
+            text.embed_tokens(ids, add_pos=False)
+    assert text.embed_tokens(ok, add_pos=True).shape == (2, 7, cfg.text.width)  # the flag was cleared
 
 
 # ---- N > 1: two ranks (sharing the one GPU of the test box, gloo transport) ----------------------
@@ -596,10 +613,13 @@ def test_fp16_encode_image_meets_1e3(eng):
     assert torch.equal(emb, tower.encode_image(images.to(DEV)))
 
 
-def test_fp16_text_tower_stays_bf16(eng):
+def test_text_tower_precision_beside_the_image_tower_modes(eng):
+    """fp16 / fp8 are image-tower precisions: the differentiated text tower runs split-bf16 beside the IEEE-half image
+    tower (the 1e-3 mode) and plain bf16 beside the fp8 one (the throughput mode)."""
     cfg = configs.get_config("tiny")
     sd = synth.make_state_dict(cfg, seed=2)
-    assert eng.TextTower(cfg, sd, DEV, "fp16").precision == "bf16"
+    assert eng.TextTower(cfg, sd, DEV, "fp16").precision == "bf16x3"
+    assert eng.TextTower(cfg, sd, DEV, "fp8").precision == "bf16"
 
 
 def test_text_feature_cache_is_opt_in_and_invalidates():

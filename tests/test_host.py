@@ -59,6 +59,8 @@ gathered = all_gather_rows(full[lo:hi].clone())
 assert torch.equal(gathered, full), "all-gather must restore the global batch in rank-major order"
 logits = 14.2857 * gathered @ txt.t()
 assert torch.allclose(logits, 14.2857 * full @ txt.t())
+labels = torch.arange(8) * 3 % 5                                               # int64 labels travel the same way
+assert torch.equal(all_gather_rows(labels[lo:hi].clone()), labels)
 dist.barrier(); dist.destroy_process_group()
 print("ok", rank)
 """
@@ -144,3 +146,48 @@ print("ok")
 """ % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_pretrained_weights_never_get_the_hash_tokenizer_silently(tmp_path, monkeypatch):
+    """real CLIP weights + the crc32 stand-in tokenizer = arbitrary token ids.  `CLIPWrapper(pretrained_path=...)`
+    needs a BPE vocabulary (argument, $TAPCLIP_BPE_PATH or an installed open_clip's copy) or an explicit tokenizer="hash";
+    the check runs before any GPU work, so it is testable here."""
+    from tap_clip_amd.models import CLIPWrapper
+    from tap_clip_amd.models.clip_wrapper import HashTokenizer
+    from tap_clip_amd.tokenizer import BPETokenizer
+
+    cfg = configs.get_config("tiny")
+    ckpt = tmp_path / "open_clip_pytorch_model.bin"
+    torch.save(synth.make_state_dict(cfg, seed=2), ckpt)
+    monkeypatch.delenv("TAPCLIP_BPE_PATH", raising=False)
+    with pytest.raises(ValueError, match="BPE vocabulary"):
+        CLIPWrapper("tiny", str(ckpt), "cpu")
+    # explicit stand-in: passes the tokenizer check and only then meets the missing GPU
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        CLIPWrapper("tiny", str(ckpt), "cpu", tokenizer="hash")
+    with pytest.raises(ValueError, match="tokenizer must be"):
+        CLIPWrapper("tiny", str(ckpt), "cpu", tokenizer="wordpiece")
+    vocab = tmp_path / "bpe.txt"
+    vocab.write_text("#version: test\nm u\nmu g</w>\n")
+    monkeypatch.setenv("TAPCLIP_BPE_PATH", str(vocab))
+    with pytest.raises(RuntimeError, match="no CPU path"):   # vocabulary found through the environment: check passed
+        CLIPWrapper("tiny", str(ckpt), "cpu")
+    pick = CLIPWrapper._pick_tokenizer
+    holder = type("H", (), {"cfg": cfg})()
+    assert isinstance(pick(holder, None, None, True), BPETokenizer)
+    monkeypatch.delenv("TAPCLIP_BPE_PATH")
+    assert isinstance(pick(holder, None, None, False), HashTokenizer)      # synthetic weights: the stand-in is the default
+    assert isinstance(pick(holder, None, str(vocab), False), BPETokenizer)
+    fn = lambda text: torch.zeros(1, 77, dtype=torch.long)
+    assert pick(holder, fn, None, True) is fn
+
+
+def test_bpe_pattern_uses_unicode_classes(tmp_path):
+    """CLIP splits on \\p{L}+ / \\p{N}: letters of any script stay one word, every digit is its own token."""
+    from tap_clip_amd.tokenizer import BPETokenizer
+
+    vocab = tmp_path / "bpe.txt"
+    vocab.write_text("#version: test\n")
+    tok = BPETokenizer(str(vocab), context_length=16, n_merges=0)
+    words = tok.pat.findall("caf\u00e9 42 na\u00efve!")
+    assert words == ["caf\u00e9", "4", "2", "na\u00efve", "!"]
