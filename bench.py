@@ -61,6 +61,24 @@ def encoder_flops_per_image(cfg):
     return v.layers * block + patch + 2 * d * cfg.embed_dim
 
 
+def cgroup_cpu_quota():
+    """CPUs the container may use per its cgroup quota (v2 cpu.max, v1 cpu.cfs_quota_us), or None without a quota."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, int(int(q) / int(per)))
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, q // per)
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +97,7 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
 
+    t_start = time.perf_counter()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -353,12 +372,18 @@ def main():
     # reference for the logits error of every GPU precision below.
     oracle_logits = None
     n_ref = min(32, args.batch)
+    print(f"[bench] GPU legs done at {time.perf_counter() - t_start:.1f}s", file=sys.stderr, flush=True)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import clip_ref, full_model_ref  # the CPU port, timed as the baseline / used as the checker only
 
         ncpu_os = os.cpu_count() or 1
         ncpu_aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else ncpu_os
-        ncpu = int(os.environ.get("TAPCLIP_CPU_THREADS", str(ncpu_aff)))  # default: every core this process may use
+        ncpu_quota = cgroup_cpu_quota()
+        # default: the cores this process may really run on -- its affinity mask, cut to the container's CPU quota when
+        # one is visible, and to 16: the pool gives a 1-GPU job a 16-core share of the host, and more threads than the
+        # share only thrash (TAPCLIP_CPU_THREADS overrides).  The real counts are printed beside the used one ("host").
+        ncpu = min(ncpu_aff, ncpu_quota or ncpu_aff, 16)
+        ncpu = int(os.environ.get("TAPCLIP_CPU_THREADS", str(ncpu)))
         torch.set_num_threads(ncpu)
         sample = images[:n_ref].cpu()
         sd_v = {k: v for k, v in sd.items() if k.startswith("visual.")}
@@ -394,7 +419,7 @@ def main():
             pass
         result["cpu_baseline"] = {"value": round(n_ref / med, 2), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
                                   "sample": f"oracle/clip_ref.py encode_image fp32, {args.model}, batch {n_ref} (of the {args.batch}), median of 3 after 1 warm-up",
-                                  "host": {"os_cpu_count": ncpu_os, "affinity_cpus": ncpu_aff, "threads_used": torch.get_num_threads(), "cpu_model": cpu_model},
+                                  "host": {"os_cpu_count": ncpu_os, "affinity_cpus": ncpu_aff, "cgroup_cpu_quota": ncpu_quota, "threads_used": torch.get_num_threads(), "cpu_model": cpu_model},
                                   "rows": {
                                       "cfg1_literal_loop": {"workload": "BASELINE configs[0]: ViT-B-32, batch 8, 10 classes, P=5 (T=82), literal per-sample attribution loop (oracle/full_model_ref.forward_literal), 1 run",
                                                             "seconds": round(t_lit, 3), "logits_per_sec": round(80 / t_lit, 2), "images_per_sec": round(8 / t_lit, 3)},
@@ -403,6 +428,7 @@ def main():
                                                                  "seconds": round(t_full, 3), "logits_per_sec": round(n_ref * args.classes / t_full, 1),
                                                                  "images_per_sec": round(n_ref / t_full, 2)}}}
 
+    print(f"[bench] CPU baseline done at {time.perf_counter() - t_start:.1f}s", file=sys.stderr, flush=True)
     if rank == 0 and world == 1 and not args.no_precisions:
         # Every precision of the towers on the same step (fewer steps): img/s, the live embedding error against the
         # split-bf16 parity mode, and the LOGITS error of the whole FullModel forward (image + text towers + attribution)
@@ -444,6 +470,7 @@ def main():
                     row["meets_1e-3"] = bool(err.max() / oracle_logits.abs().max() < 1e-3)
                     del fm
                 table[prec] = row
+                print(f"[bench] precision {prec} done at {time.perf_counter() - t_start:.1f}s", file=sys.stderr, flush=True)
                 if not own:
                     del cw, tw
                     torch.cuda.empty_cache()

@@ -95,12 +95,12 @@ def _rb(x: torch.Tensor, emulate: Optional[str]) -> torch.Tensor:
     """Round-trip through the emulated operand dtype (identity for fp32)."""
     if emulate is None:
         return x
-    if emulate == "bf16":
-        return x.to(torch.bfloat16).to(torch.float32)
+    if emulate == "bf16":  # (back to x's own dtype: the emulation also runs in float64, see emulation_floor)
+        return x.to(torch.bfloat16).to(x.dtype)
     if emulate == "fp16":
-        return x.to(torch.float16).to(torch.float32)
+        return x.to(torch.float16).to(x.dtype)
     if emulate == "mx8":  # the fp8 path keeps bf16 wherever it is not an MXFP8 GEMM operand
-        return x.to(torch.bfloat16).to(torch.float32)
+        return x.to(torch.bfloat16).to(x.dtype)
     raise ValueError(emulate)
 
 
@@ -200,6 +200,25 @@ def block_forward(
     if taps is not None:
         taps["out"] = x
     return x, (p if want_probs else None)
+
+
+def emulation_floor(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str, heads: int, emulate: str = "bf16"):
+    """How closely ANY two implementations that round at the same points can agree on one block: the emulation with
+    fp32 accumulation against the same emulation with fp64 accumulation, per tap, as (rel_l2, rel_max).
+
+    Two pipelines whose pre-rounding values differ by a relative eps disagree on a fraction ~eps/u of the rounded
+    elements by one whole step u (2^-8 relative for bf16), i.e. by sqrt(eps * u) in rms -- far more than eps -- and the
+    next rounding stage amplifies again: 1e-7 -> 2e-5 (q|k|v) -> 2e-4 (attention output) -> 6e-4 (out_proj) -> 1.1e-3
+    rel-L2 / 3e-3 rel-max at the block output (ViT-B widths).  Round 1's kernels measured exactly these numbers against
+    the emulation (gpurun_out/t9.log): that gap is this floor, not a rounding point that differs."""
+    t32, t64 = {}, {}
+    block_forward(x, sd, prefix, heads, emulate=emulate, taps=t32)
+    block_forward(x.double(), {k: v.double() for k, v in sd.items() if k.startswith(prefix)}, prefix, heads, emulate=emulate, taps=t64)
+    out = {}
+    for k in t32:
+        a, b = t32[k].double(), t64[k]
+        out[k] = (float((a - b).norm() / b.norm()), float((a - b).abs().max() / b.abs().max()))
+    return out
 
 
 def transformer_forward(

@@ -235,3 +235,20 @@ def test_oracle_mx8_and_fp16_emulation_modes_run():
             out = clip_ref.encode_image(images, sd, cfg, emulate=mode)
             err = float((out - ref).norm() / ref.norm())
             assert 0 < err < bound, (mode, err)
+
+
+def test_emulation_floor_of_chained_bf16_rounding():
+    """Why the bf16 kernels are compared with `emulate="bf16"` at ~1e-3 and not at 1e-6: the emulation with fp32
+    accumulation against the same emulation with fp64 accumulation (identical rounding points) already differs by
+    ~1e-3 rel-L2 / ~3e-3 rel-max after one block, growing stage by stage as sqrt(eps * 2^-8)."""
+    g = golden("block_vision")
+    d, heads, mlp, n, T = (int(g[k]) for k in ("d", "heads", "mlp", "n", "T"))
+    sd = {}
+    synth._tower(sd, "transformer.", d, 1, mlp, seed=int(g["seed_weights"]))
+    x = synth.normal([n, T, d], int(g["seed_x"]), "block.vision.x")
+    with torch.no_grad():
+        floor = clip_ref.emulation_floor(x, sd, "transformer.resblocks.0.", heads)
+    l2 = {k: v[0] for k, v in floor.items()}
+    assert l2["ln_1"] < 1e-6                                  # nothing rounded yet: plain fp32 vs fp64
+    assert l2["ln_1"] < l2["qkv"] < l2["attn_ctx"] < l2["attn_out"] < l2["out"]   # each rounding stage amplifies
+    assert 3e-4 < l2["out"] < 2e-3 and 1e-3 < floor["out"][1] < 6e-3
