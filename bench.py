@@ -247,13 +247,17 @@ def main():
         if ln and ln[1]:
             rows = args.batch * cfg.n_tokens
             rd = rows * cfg.vision.width
-            # ln_pre (fp32 -> fp32: 8 B/element), LN1 of block 0 (fp32 -> bf16: 6), LN2 of blocks 0..L-2 (read x + one
-            # branch, write the bf16 output only: 8), LN2 of the last block (also writes x: 12), LN1 of blocks 1..L-1
-            # (read x + two branches, write x + output: 14).  (fp8: the output is 1.03 B instead of 2; not modelled.)
+            # fp32 residual (bf16x3, or TAPCLIP_NO_X24): ln_pre (fp32 -> fp32: 8 B/element), LN1 of block 0 (fp32 -> bf16: 6),
+            # LN2 of blocks 0..L-2 (read x + one branch, write the 16-bit output only: 8), LN2 of the last block (also
+            # writes x: 12), LN1 of blocks 1..L-1 (read x + two branches, write x + output: 14).
+            # 24-bit residual planes (the 16-bit modes, layernorm.hip XF = 2): ln_pre + LN1 of block 0 in one kernel
+            # (read fp32, write planes + output: 9), LN2 7 / 10, LN1 12.  (fp8: 16-bit stream, 1.03-B outputs; not modelled.)
             L = cfg.vision.layers
-            ln_bytes = rd * (8 + 6 + (L - 1) * 8 + 12 + (L - 1) * 14)
+            x24 = args.precision in ("bf16", "fp16") and cfg.vision.width % 256 == 0 and not os.environ.get("TAPCLIP_NO_X24")
+            per_elt = (9 + (L - 1) * 7 + 10 + (L - 1) * 12) if x24 else (8 + 6 + (L - 1) * 8 + 12 + (L - 1) * 14)
+            ln_bytes = rd * per_elt
             result["layernorm_hbm"] = {"achieved_GBps": round(ln_bytes * args.steps / (ln[0] * 1e-3) / 1e9, 1), "peak_GBps": HBM_PEAK_GBS,
-                                       "bytes_per_step": ln_bytes}
+                                       "bytes_per_step": ln_bytes, "residual_stream": "24-bit planes" if x24 else "fp32"}
         result["kernels"] = kern
 
     if rank == 0 and world == 1 and not args.no_full_forward:

@@ -90,6 +90,13 @@ hipError_t launch_add_layernorm_ex(int add, float* x, const bf16_t* d1_hi, const
 hipError_t launch_layernorm_mx8(int add, float* x, bf16_t* x16, const bf16_t* d1_hi, const bf16_t* d2_hi, const float* gamma,
                                 const float* beta, int64_t rows, int32_t d, uint8_t* out_q, uint8_t* out_sc, int64_t rows_pad, hipStream_t s);
 // out[b, :] = x16[b * tokens, :] + delta[b * tokens, :]  (the CLS rows of a 16-bit residual stream, as fp32 [B, D])
+// 24-bit residual stream of the image tower's 16-bit modes (layernorm.hip XF = 2): planes xhi [rows, d] u16 + xlo [rows, d] u8
+bool layernorm_x24_supports(int32_t d);
+hipError_t launch_layernorm_x24(int add, int pre, const float* src_f32, int64_t ld_src, bf16_t* xhi, uint8_t* xlo, const bf16_t* d1,
+                                const bf16_t* d2, const float* gamma_pre, const float* beta_pre, const float* gamma, const float* beta,
+                                int64_t rows, int32_t d, bf16_t* out, hipStream_t s);
+hipError_t launch_gather_cls24(const bf16_t* xhi, const uint8_t* xlo, const bf16_t* delta, int32_t B, int32_t tokens, int32_t D, float* out,
+                               hipStream_t s);
 hipError_t launch_gather_cls16(const bf16_t* x16, const bf16_t* delta, int32_t B, int32_t tokens, int32_t D, float* out, hipStream_t s);
 // Resize(size, bicubic) + CenterCrop(size) + ToTensor + Normalize of B packed uint8 RGB images (preprocess.hip).
 // desc [B][4] int64 (device): byte offset of the image in `pixels`, height, width, byte offset of its height*size*3

@@ -14,28 +14,86 @@ namespace {
 //   1  x += d1, written back            2  x + d1 normalised, x NOT written back (LN2: saves 4 of 12 B/element)
 //   3  x += d1 + d2, written back       (the next block's LN1 then folds both branches: 14 B/element; a block's two
 //                                        LayerNorms move 22 B/element instead of 24)
-// XH: the residual stream itself is 16-bit (x16, row stride d) instead of fp32 x -- the fp8 precision only, where
-// a 2^-9 rounding of x per block is far below the MXFP8 operand error and the LayerNorms are 20 % of the step.
-template <int MODE, int NV, int ADD, bool XH = false>  // NV float4 per lane: d = 256 * NV
-__global__ __launch_bounds__(256) void ln_vec_kernel(float* __restrict__ x, int64_t ldx, bf16_t* __restrict__ x16,
+// XF: the format of the residual stream (row stride d when not fp32):
+//   0  fp32 x
+//   1  16-bit x16 (bf16 / IEEE half) -- the fp8 precision only, where a 2^-9 rounding of x per block is far below the
+//      MXFP8 operand error and the LayerNorms are 20 % of the step
+//   2  "x24": the fp32 value rounded (nearest-even) to 16 significand bits and kept as two planes, x16 = its upper 16
+//      bits and x8 = the next 8: 3 bytes per element at 2^-17 relative rounding (2e-5 over the 24 roundings of ViT-B:
+//      a tenth of the IEEE-half operand error of the "fp16" mode, 1 % of bf16's).  The image tower's 16-bit modes use
+//      it: the LayerNorm kernels are HBM-bound (6 TB/s) and their bytes drop 14 -> 12 (LN1) and 8 -> 7 (LN2).
+// PRE (XF = 2, ADD = 0): the row is first read as fp32 from x, normalised with (gamma_pre, beta_pre) -- ln_pre of the
+//   image tower -- and THAT is the residual row, written in the XF format; then the LayerNorm proper (block 0's ln_1)
+//   runs on it: one pass over the patch embeddings instead of an in-place fp32 ln_pre followed by a second kernel.
+__device__ __forceinline__ uint32_t x24_bits(float v) {  // fp32 bits rounded to nearest-even at bit 8
+  const uint32_t u = __float_as_uint(v);
+  return u + 0x7Fu + ((u >> 8) & 1u);
+}
+__device__ __forceinline__ void x24_store(bf16_t* hi, uint8_t* lo, const float4& v) {
+  const uint32_t a = x24_bits(v.x), b = x24_bits(v.y), c = x24_bits(v.z), e = x24_bits(v.w);
+  *reinterpret_cast<uint2*>(hi) = make_uint2((a >> 16) | (b & 0xFFFF0000u), (c >> 16) | (e & 0xFFFF0000u));
+  *reinterpret_cast<uint32_t*>(lo) = ((a >> 8) & 0xFFu) | (b & 0xFF00u) | ((c << 8) & 0xFF0000u) | ((e << 16) & 0xFF000000u);
+}
+__device__ __forceinline__ float4 x24_load(const bf16_t* hi, const uint8_t* lo) {
+  const uint2 h = *reinterpret_cast<const uint2*>(hi);
+  const uint32_t l = *reinterpret_cast<const uint32_t*>(lo);
+  return make_float4(__uint_as_float((h.x << 16) | ((l << 8) & 0xFF00u)), __uint_as_float((h.x & 0xFFFF0000u) | (l & 0xFF00u)),
+                     __uint_as_float((h.y << 16) | ((l >> 8) & 0xFF00u)), __uint_as_float((h.y & 0xFFFF0000u) | ((l >> 16) & 0xFF00u)));
+}
+
+template <int MODE, int NV, int ADD, int XF = 0, bool PRE = false>  // NV float4 per lane: d = 256 * NV
+__global__ __launch_bounds__(256) void ln_vec_kernel(float* __restrict__ x, int64_t ldx, bf16_t* __restrict__ x16, uint8_t* __restrict__ x8,
                                                      const bf16_t* __restrict__ d_hi, const bf16_t* __restrict__ d_lo,
                                                      const bf16_t* __restrict__ e_hi, const bf16_t* __restrict__ e_lo,
+                                                     const float* __restrict__ gamma_pre, const float* __restrict__ beta_pre,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, int64_t rows, int d,
                                                      bf16_t* out_hi, bf16_t* out_lo, float* out_f32,
                                                      uint8_t* out_q, uint8_t* out_sc, int64_t rows_pad) {
+  static_assert(!PRE || (XF == 2 && ADD == 0), "PRE: fp32 source -> x24 residual");
+  constexpr bool XH = XF == 1;
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  float* xr = XH ? nullptr : x + row * ldx;
+  float* xr = (XF != 0 && !PRE) ? nullptr : x + row * ldx;
   float4 v[NV];
   float s = 0.f;
+  if (PRE) {  // ln_pre in registers; its output is the residual row
+    float s0 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      v[j] = *reinterpret_cast<const float4*>(xr + 4 * lane + 256 * j);
+      s0 += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+    const float mean0 = wave_sum(s0) / (float)d;
+    float ss0 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      v[j].x -= mean0; v[j].y -= mean0; v[j].z -= mean0; v[j].w -= mean0;
+      ss0 += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+    }
+    const float rstd0 = rsqrtf(wave_sum(ss0) / (float)d + 1e-5f);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = 4 * lane + 256 * j;
+      const float4 gm = *reinterpret_cast<const float4*>(gamma_pre + c);
+      const float4 bt = *reinterpret_cast<const float4*>(beta_pre + c);
+      v[j] = make_float4(v[j].x * rstd0 * gm.x + bt.x, v[j].y * rstd0 * gm.y + bt.y, v[j].z * rstd0 * gm.z + bt.z, v[j].w * rstd0 * gm.w + bt.w);
+      x24_store(x16 + row * d + c, x8 + row * d + c, v[j]);
+      // the blocks read the residual back from its 24-bit planes: normalise exactly what they will see
+      v[j] = make_float4(__uint_as_float(x24_bits(v[j].x) & 0xFFFFFF00u), __uint_as_float(x24_bits(v[j].y) & 0xFFFFFF00u),
+                         __uint_as_float(x24_bits(v[j].z) & 0xFFFFFF00u), __uint_as_float(x24_bits(v[j].w) & 0xFFFFFF00u));
+    }
+  }
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int c = 4 * lane + 256 * j;
-    if (XH) {
+    if (PRE) {
+    } else if (XH) {
       const uint2 h = *reinterpret_cast<const uint2*>(x16 + row * d + c);
       v[j] = make_float4(bf2f((bf16_t)(h.x & 0xFFFF)), bf2f((bf16_t)(h.x >> 16)), bf2f((bf16_t)(h.y & 0xFFFF)), bf2f((bf16_t)(h.y >> 16)));
+    } else if (XF == 2) {
+      v[j] = x24_load(x16 + row * d + c, x8 + row * d + c);
     } else {
       v[j] = *reinterpret_cast<const float4*>(xr + c);
     }
@@ -53,6 +111,7 @@ __global__ __launch_bounds__(256) void ln_vec_kernel(float* __restrict__ x, int6
       }
       if (ADD != 2) {
         if (XH) *reinterpret_cast<uint2*>(x16 + row * d + c) = make_uint2(pack_bf2(v[j].x, v[j].y), pack_bf2(v[j].z, v[j].w));
+        else if (XF == 2) x24_store(x16 + row * d + c, x8 + row * d + c, v[j]);
         else *reinterpret_cast<float4*>(xr + c) = v[j];
       }
     }
@@ -168,10 +227,10 @@ hipError_t launch_mode(float* x, int64_t ldx, const bf16_t* dh, const bf16_t* dl
     if constexpr (MODE == 3) {
       if (d % 256 != 0 || d / 256 > 4) return hipErrorInvalidValue;
       switch (d / 256) {
-        case 1: hipLaunchKernelGGL((ln_vec_kernel<3, 1, ADD, true>), grid, block, 0, s, nullptr, 0, x16, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
-        case 2: hipLaunchKernelGGL((ln_vec_kernel<3, 2, ADD, true>), grid, block, 0, s, nullptr, 0, x16, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
-        case 3: hipLaunchKernelGGL((ln_vec_kernel<3, 3, ADD, true>), grid, block, 0, s, nullptr, 0, x16, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
-        default: hipLaunchKernelGGL((ln_vec_kernel<3, 4, ADD, true>), grid, block, 0, s, nullptr, 0, x16, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+        case 1: hipLaunchKernelGGL((ln_vec_kernel<3, 1, ADD, 1>), grid, block, 0, s, nullptr, 0, x16, nullptr, dh, dl, eh, el, nullptr, nullptr, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+        case 2: hipLaunchKernelGGL((ln_vec_kernel<3, 2, ADD, 1>), grid, block, 0, s, nullptr, 0, x16, nullptr, dh, dl, eh, el, nullptr, nullptr, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+        case 3: hipLaunchKernelGGL((ln_vec_kernel<3, 3, ADD, 1>), grid, block, 0, s, nullptr, 0, x16, nullptr, dh, dl, eh, el, nullptr, nullptr, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+        default: hipLaunchKernelGGL((ln_vec_kernel<3, 4, ADD, 1>), grid, block, 0, s, nullptr, 0, x16, nullptr, dh, dl, eh, el, nullptr, nullptr, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
       }
       return hipGetLastError();
     } else {
@@ -180,10 +239,10 @@ hipError_t launch_mode(float* x, int64_t ldx, const bf16_t* dh, const bf16_t* dl
   }
   if (d % 256 == 0 && d / 256 <= 4 && ldx % 4 == 0) {
     switch (d / 256) {
-      case 1: hipLaunchKernelGGL((ln_vec_kernel<MODE, 1, ADD>), grid, block, 0, s, x, ldx, nullptr, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
-      case 2: hipLaunchKernelGGL((ln_vec_kernel<MODE, 2, ADD>), grid, block, 0, s, x, ldx, nullptr, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
-      case 3: hipLaunchKernelGGL((ln_vec_kernel<MODE, 3, ADD>), grid, block, 0, s, x, ldx, nullptr, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
-      default: hipLaunchKernelGGL((ln_vec_kernel<MODE, 4, ADD>), grid, block, 0, s, x, ldx, nullptr, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+      case 1: hipLaunchKernelGGL((ln_vec_kernel<MODE, 1, ADD>), grid, block, 0, s, x, ldx, nullptr, nullptr, dh, dl, eh, el, nullptr, nullptr, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+      case 2: hipLaunchKernelGGL((ln_vec_kernel<MODE, 2, ADD>), grid, block, 0, s, x, ldx, nullptr, nullptr, dh, dl, eh, el, nullptr, nullptr, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+      case 3: hipLaunchKernelGGL((ln_vec_kernel<MODE, 3, ADD>), grid, block, 0, s, x, ldx, nullptr, nullptr, dh, dl, eh, el, nullptr, nullptr, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+      default: hipLaunchKernelGGL((ln_vec_kernel<MODE, 4, ADD>), grid, block, 0, s, x, ldx, nullptr, nullptr, dh, dl, eh, el, nullptr, nullptr, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
     }
   } else {
     if constexpr (MODE == 3) return hipErrorInvalidValue;  // MXFP8 output: widths 256 .. 1024 only
@@ -229,6 +288,65 @@ hipError_t launch_add_layernorm_ex(int add, float* x, const bf16_t* d1_hi, const
   if (rows <= 0 || d <= 0 || d % 64 != 0 || add < 1 || add > 3 || d1_hi == nullptr || (add == 3 && d2_hi == nullptr)) return hipErrorInvalidValue;
   if (out_lo != nullptr) return launch_add_mode<1>(add, x, d1_hi, d1_lo, d2_hi, d2_lo, gamma, beta, rows, d, out_hi, out_lo, s);
   return launch_add_mode<0>(add, x, d1_hi, nullptr, d2_hi, nullptr, gamma, beta, rows, d, out_hi, nullptr, s);
+}
+
+// ---- 24-bit residual stream (XF = 2; the image tower's bf16 / IEEE-half modes).  bf16 output only.
+//   pre != 0: src_f32 [rows, d] (row stride ld_src) -> ln_pre -> residual planes (xhi, xlo) -> LayerNorm(gamma, beta) -> out
+//   add = 1, 2, 3 as launch_add_layernorm_ex, on the planes
+namespace {
+template <int ADD, bool PRE>
+hipError_t launch_x24_t(const float* src, int64_t ld_src, bf16_t* xhi, uint8_t* xlo, const bf16_t* d1, const bf16_t* d2, const float* gp,
+                        const float* bp, const float* gamma, const float* beta, int64_t rows, int32_t d, bf16_t* out, hipStream_t s) {
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  float* x = const_cast<float*>(src);
+  switch (d / 256) {
+    case 1: hipLaunchKernelGGL((ln_vec_kernel<0, 1, ADD, 2, PRE>), grid, block, 0, s, x, ld_src, xhi, xlo, d1, nullptr, d2, nullptr, gp, bp, gamma, beta, rows, d, out, nullptr, nullptr, nullptr, nullptr, 0); break;
+    case 2: hipLaunchKernelGGL((ln_vec_kernel<0, 2, ADD, 2, PRE>), grid, block, 0, s, x, ld_src, xhi, xlo, d1, nullptr, d2, nullptr, gp, bp, gamma, beta, rows, d, out, nullptr, nullptr, nullptr, nullptr, 0); break;
+    case 3: hipLaunchKernelGGL((ln_vec_kernel<0, 3, ADD, 2, PRE>), grid, block, 0, s, x, ld_src, xhi, xlo, d1, nullptr, d2, nullptr, gp, bp, gamma, beta, rows, d, out, nullptr, nullptr, nullptr, nullptr, 0); break;
+    default: hipLaunchKernelGGL((ln_vec_kernel<0, 4, ADD, 2, PRE>), grid, block, 0, s, x, ld_src, xhi, xlo, d1, nullptr, d2, nullptr, gp, bp, gamma, beta, rows, d, out, nullptr, nullptr, nullptr, nullptr, 0); break;
+  }
+  return hipGetLastError();
+}
+}  // namespace
+
+bool layernorm_x24_supports(int32_t d) { return d % 256 == 0 && d >= 256 && d <= 1024; }
+
+hipError_t launch_layernorm_x24(int add, int pre, const float* src_f32, int64_t ld_src, bf16_t* xhi, uint8_t* xlo, const bf16_t* d1,
+                                const bf16_t* d2, const float* gamma_pre, const float* beta_pre, const float* gamma, const float* beta,
+                                int64_t rows, int32_t d, bf16_t* out, hipStream_t s) {
+  if (rows <= 0 || !layernorm_x24_supports(d) || !xhi || !xlo || !out || !gamma || !beta) return hipErrorInvalidValue;
+  if (pre) {
+    if (add != 0 || !src_f32 || !gamma_pre || !beta_pre || ld_src % 4 != 0) return hipErrorInvalidValue;
+    return launch_x24_t<0, true>(src_f32, ld_src, xhi, xlo, nullptr, nullptr, gamma_pre, beta_pre, gamma, beta, rows, d, out, s);
+  }
+  if ((add >= 1 && !d1) || (add == 3 && !d2)) return hipErrorInvalidValue;
+  switch (add) {
+    case 0: return launch_x24_t<0, false>(nullptr, 0, xhi, xlo, nullptr, nullptr, nullptr, nullptr, gamma, beta, rows, d, out, s);
+    case 1: return launch_x24_t<1, false>(nullptr, 0, xhi, xlo, d1, nullptr, nullptr, nullptr, gamma, beta, rows, d, out, s);
+    case 2: return launch_x24_t<2, false>(nullptr, 0, xhi, xlo, d1, nullptr, nullptr, nullptr, gamma, beta, rows, d, out, s);
+    case 3: return launch_x24_t<3, false>(nullptr, 0, xhi, xlo, d1, d2, nullptr, nullptr, gamma, beta, rows, d, out, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// CLS rows of the 24-bit residual (+ the pending c_proj branch) -> fp32 [B, D] for the pool / ln_post / proj kernel
+namespace {
+__global__ void gather_cls24_kernel(const bf16_t* __restrict__ xhi, const uint8_t* __restrict__ xlo, const bf16_t* __restrict__ delta,
+                                    int tokens, int D, int64_t total, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t b = i / D;
+  const int64_t src = b * tokens * (int64_t)D + (i - b * D);
+  const float v = __uint_as_float(((uint32_t)xhi[src] << 16) | ((uint32_t)xlo[src] << 8));
+  out[i] = v + (delta ? bf2f(delta[src]) : 0.f);
+}
+}  // namespace
+
+hipError_t launch_gather_cls24(const bf16_t* xhi, const uint8_t* xlo, const bf16_t* delta, int32_t B, int32_t tokens, int32_t D, float* out,
+                               hipStream_t s) {
+  const int64_t total = (int64_t)B * D;
+  hipLaunchKernelGGL(gather_cls24_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xhi, xlo, delta, tokens, D, total, out);
+  return hipGetLastError();
 }
 
 // MXFP8 output (the A operand of the fp8 path's QKV / c_fc GEMMs): out_q [rows, d] e4m3, out_sc [d/64][rows_pad][2].

@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <set>
@@ -77,6 +78,7 @@ struct tapclip_tower {
   tapclip_tower_cfg cfg;
   bool split = false;
   bool fp8 = false;       // TAPCLIP_PREC_FP8: block GEMMs on MXFP8 (image tower only)
+  bool x24 = false;       // image tower, bf16 / IEEE-half modes: the residual stream of the blocks in 24-bit planes (layernorm.hip XF = 2)
   int tokens_vision = 0;  // G*G + 1
   int Kp = 0;             // padded 3*p*p
   std::vector<LayerW> layers;
@@ -113,6 +115,8 @@ struct Workspace {
   // scales [K/64][m_pad][2]: 1.03 bytes per element against 2)
   uint8_t *xn_q = nullptr, *xn_s = nullptr, *ao_q = nullptr, *ao_s = nullptr, *h_q = nullptr, *h_s = nullptr;
   bf16_t* x16 = nullptr;  // fp8 precision: the residual stream of the blocks is 16-bit
+  bf16_t* x24_hi = nullptr;  // x24: upper 16 bits of the residual stream
+  uint8_t* x24_lo = nullptr;  //      next 8 bits
   int64_t m_pad = 0;
   size_t bytes = 0;
 };
@@ -161,6 +165,10 @@ Workspace carve(const tapclip_tower* t, int64_t n_seq, int tokens, void* base) {
     view(w.h_hi, F, w.h_q, w.h_s);
     w.x16 = static_cast<bf16_t*>(take(M * D * 2));
   }
+  if (t->x24) {
+    w.x24_hi = static_cast<bf16_t*>(take(M * D * 2));
+    w.x24_lo = static_cast<uint8_t*>(take(M * D));
+  }
   w.bytes = off;
   return w;
 }
@@ -180,6 +188,12 @@ struct ProfScope {
     rec = &t->prof[t->prof_used++];
     rec->slot = slot;
     (void)hipEventRecord(rec->start, s);
+  }
+  void cancel() {  // nothing was launched inside this scope after all: give the record back
+    if (rec) {
+      --t->prof_used;
+      rec = nullptr;
+    }
   }
   ~ProfScope() {
     if (rec) (void)hipEventRecord(rec->stop, s);
@@ -326,6 +340,7 @@ int run_blocks_fp8(tapclip_tower* t, int64_t n_seq, int tokens, const Workspace&
 // N = 768).  On return the last c_proj branch is still pending in w.d: the caller folds it in.
 int run_blocks(tapclip_tower* t, float* x, int64_t n_seq, int tokens, int causal, const Workspace& w,
                float* probs_last, float* attn_out_last, hipStream_t s) {
+  const bool x24 = t->x24 && t->cfg.kind == TAPCLIP_TOWER_VISION;  // residual stream in w.x24_hi / w.x24_lo instead of x
   const int64_t M = n_seq * tokens;
   const int D = t->cfg.width, F = t->cfg.mlp_dim, H = t->cfg.heads;
   for (int li = 0; li < t->cfg.layers; ++li) {
@@ -334,7 +349,11 @@ int run_blocks(tapclip_tower* t, float* x, int64_t n_seq, int tokens, int causal
     {
       ProfScope ps(t, 1, s);
       // block l > 0: x still lacks BOTH branches of block l - 1 (its LN2 did not write x back)
-      if (li == 0) HIP_TRY(launch_layernorm(x, D, L.ln1_g, L.ln1_b, M, D, w.xn_hi, w.xn_lo, nullptr, s));
+      if (x24) {
+        // (block 0: ln_pre + this LayerNorm were one kernel, launched by the caller)
+        if (li == 0) ps.cancel();
+        else HIP_TRY(launch_layernorm_x24(3, 0, nullptr, 0, w.x24_hi, w.x24_lo, w.a_hi, w.d_hi, nullptr, nullptr, L.ln1_g, L.ln1_b, M, D, w.xn_hi, s));
+      } else if (li == 0) HIP_TRY(launch_layernorm(x, D, L.ln1_g, L.ln1_b, M, D, w.xn_hi, w.xn_lo, nullptr, s));
       else HIP_TRY(launch_add_layernorm_ex(3, x, w.a_hi, w.a_lo, w.d_hi, w.d_lo, L.ln1_g, L.ln1_b, M, D, w.xn_hi, w.xn_lo, s));
     }
     int rc = gemm(t, 2, EPI_BIAS_BF16, w.xn_hi, w.xn_lo, D, L.wqkv, L.bqkv, M, 3 * D, D, w.qkv_hi, w.qkv_lo, nullptr,
@@ -360,7 +379,8 @@ int run_blocks(tapclip_tower* t, float* x, int64_t n_seq, int tokens, int causal
       ProfScope ps(t, 1, s);
       // LN2 normalises x + branch without writing x back (8 instead of 12 B/element); the last block does write,
       // so that only c_proj's branch is pending on return
-      HIP_TRY(launch_add_layernorm_ex(last ? 1 : 2, x, w.a_hi, w.a_lo, nullptr, nullptr, L.ln2_g, L.ln2_b, M, D, w.xn_hi, w.xn_lo, s));
+      if (x24) HIP_TRY(launch_layernorm_x24(last ? 1 : 2, 0, nullptr, 0, w.x24_hi, w.x24_lo, w.a_hi, nullptr, nullptr, nullptr, L.ln2_g, L.ln2_b, M, D, w.xn_hi, s));
+      else HIP_TRY(launch_add_layernorm_ex(last ? 1 : 2, x, w.a_hi, w.a_lo, nullptr, nullptr, L.ln2_g, L.ln2_b, M, D, w.xn_hi, w.xn_lo, s));
     }
     rc = gemm(t, 5, EPI_BIAS_GELU_BF16, w.xn_hi, w.xn_lo, D, L.wfc, L.bfc, M, F, D, w.h_hi, w.h_lo, nullptr, F, s);
     if (rc) return rc;
@@ -518,6 +538,8 @@ int tapclip_tower_create(const tapclip_tower_cfg* cfg, tapclip_tower_t** out) {
     }
     const int G = cfg->image_size / cfg->patch;
     t->tokens_vision = G * G + 1;
+    static const bool no_x24 = getenv("TAPCLIP_NO_X24") != nullptr;  // (experiments: keep the fp32 residual stream)
+    t->x24 = !t->split && !t->fp8 && layernorm_x24_supports(cfg->width) && !no_x24;
     t->Kp = (3 * cfg->patch * cfg->patch + 63) / 64 * 64;
     for (const char* k : {"conv1.weight", "class_embedding", "positional_embedding", "ln_pre.weight", "ln_pre.bias",
                           "ln_post.weight", "ln_post.bias", "proj"})
@@ -684,6 +706,8 @@ int tapclip_encode_image(tapclip_tower_t* t, const float* images, int32_t B, flo
     ProfScope ps(t, 1, s);
     // (fp8: ln_pre writes the blocks' 16-bit residual stream; else it normalises the fp32 stream in place)
     if (t->fp8) HIP_TRY(launch_layernorm(w.x, D, t->lnpre_g, t->lnpre_b, (int64_t)B * N, D, w.x16, nullptr, nullptr, s));
+    // x24: ln_pre, the write of the 24-bit residual planes and block 0's ln_1 in one pass over the patch embeddings
+    else if (t->x24) HIP_TRY(launch_layernorm_x24(0, 1, w.x, D, w.x24_hi, w.x24_lo, nullptr, nullptr, t->lnpre_g, t->lnpre_b, t->layers[0].ln1_g, t->layers[0].ln1_b, (int64_t)B * N, D, w.xn_hi, s));
     else HIP_TRY(launch_layernorm(w.x, D, t->lnpre_g, t->lnpre_b, (int64_t)B * N, D, nullptr, nullptr, w.x, s));
   }
   rc = t->fp8 ? run_blocks_fp8(t, B, N, w, s) : run_blocks(t, w.x, B, N, 0, w, nullptr, nullptr, s);
@@ -691,8 +715,10 @@ int tapclip_encode_image(tapclip_tower_t* t, const float* images, int32_t B, flo
   {
     ProfScope ps(t, 7, s);
     // the last c_proj branch is still pending: the pool kernel adds it to the CLS rows it gathers
-    if (t->fp8) {
-      HIP_TRY(launch_gather_cls16(w.x16, w.d_hi, B, N, D, w.x, s));  // [B, D] fp32 at the front of the (now free) fp32 buffer
+    if (t->fp8 || t->x24) {
+      // [B, D] fp32 at the front of the (now free) fp32 buffer
+      if (t->fp8) HIP_TRY(launch_gather_cls16(w.x16, w.d_hi, B, N, D, w.x, s));
+      else HIP_TRY(launch_gather_cls24(w.x24_hi, w.x24_lo, w.d_hi, B, N, D, w.x, s));
       HIP_TRY(launch_pool_project(w.x, nullptr, nullptr, B, 1, D, nullptr, 0, t->lnpost_g, t->lnpost_b, t->proj, t->cfg.embed_dim, normalize, out, s));
     } else {
       HIP_TRY(launch_pool_project(w.x, w.d_hi, w.d_lo, B, N, D, nullptr, 0, t->lnpost_g, t->lnpost_b, t->proj, t->cfg.embed_dim, normalize, out, s));
