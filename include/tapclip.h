@@ -111,7 +111,9 @@ int tapclip_encode_image(tapclip_tower_t* vision, const float* images, int32_t b
  *   attn_heads [n,H,T,T] fp32 softmax probabilities per head      (nullable)
  *   attn_mean  [n,T,T]   fp32 head mean                            (nullable)
  *   attn_out   [n,T,D]   fp32 output of the attention module (post out_proj, pre
- *              residual): what the hook LITERALLY captures (`output[0]`)  (nullable) */
+ *              residual): what the hook LITERALLY captures (`output[0]`)  (nullable)
+ * out_hidden == NULL: the call is for the capture only (model_wrapper.py:58 discards the
+ * transformer's output), and the last block stops after its attention. */
 int tapclip_text_forward(tapclip_tower_t* text, const float* x, int32_t n_seq, int32_t tokens,
                          int32_t causal, float* out_hidden, float* attn_heads, float* attn_mean,
                          float* attn_out, void* workspace, size_t workspace_bytes,

@@ -338,8 +338,11 @@ int run_blocks_fp8(tapclip_tower* t, int64_t n_seq, int tokens, const Workspace&
 // write their branch as bf16 (hi [+ lo]) into w.d and the next LayerNorm kernel applies x += d before
 // normalising (the fp32 read-modify-write in a GEMM epilogue cost more than the GEMM's MFMA work at
 // N = 768).  On return the last c_proj branch is still pending in w.d: the caller folds it in.
+// capture_only: the caller wants the last block's attention capture (probs_last / attn_out_last), not the hidden states
+// -- pass 1 of FullModel.forward, reference models/model_wrapper.py:57-62 discards the transformer's output -- so the last
+// block stops after its attention core (literal capture: after its fp32 out_proj).
 int run_blocks(tapclip_tower* t, float* x, int64_t n_seq, int tokens, int causal, const Workspace& w,
-               float* probs_last, float* attn_out_last, hipStream_t s) {
+               float* probs_last, float* attn_out_last, hipStream_t s, bool capture_only = false) {
   const bool x24 = t->x24 && t->cfg.kind == TAPCLIP_TOWER_VISION;  // residual stream in w.x24_hi / w.x24_lo instead of x
   const int64_t M = n_seq * tokens;
   const int D = t->cfg.width, F = t->cfg.mlp_dim, H = t->cfg.heads;
@@ -373,6 +376,7 @@ int run_blocks(tapclip_tower* t, float* x, int64_t n_seq, int tokens, int causal
       rc = gemm(t, 4, EPI_BIAS_F32, w.ao_hi, w.ao_lo, D, L.wo, L.bo, M, D, D, nullptr, nullptr, attn_out_last, D, s);
       if (rc) return rc;
     }
+    if (last && capture_only) return TAPCLIP_OK;
     rc = gemm(t, 4, EPI_BIAS_BF16, w.ao_hi, w.ao_lo, D, L.wo, L.bo, M, D, D, w.a_hi, w.a_lo, nullptr, D, s);
     if (rc) return rc;
     {
@@ -743,7 +747,7 @@ int tapclip_text_forward(tapclip_tower_t* t, const float* x_in, int32_t n_seq, i
   float* x = out_hidden ? out_hidden : w.x;  // the residual stream lives in the caller's output
   if (x != x_in) HIP_TRY(hipMemcpyAsync(x, x_in, (size_t)n_seq * tokens * D * 4, hipMemcpyDeviceToDevice, s));
   float* probs = attn_heads ? attn_heads : (attn_mean ? w.probs : nullptr);
-  rc = run_blocks(t, x, n_seq, tokens, causal, w, probs, attn_out, s);
+  rc = run_blocks(t, x, n_seq, tokens, causal, w, probs, attn_out, s, /*capture_only=*/out_hidden == nullptr);
   if (rc) return rc;
   if (out_hidden) HIP_TRY(launch_add_delta(x, w.d_hi, w.d_lo, (int64_t)n_seq * tokens * D, s));  // last pending branch
   if (attn_mean) HIP_TRY(launch_head_mean(probs, n_seq, t->cfg.heads, tokens, attn_mean, s));

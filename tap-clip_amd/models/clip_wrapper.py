@@ -77,7 +77,12 @@ class _TextTransformer(_Bag):
         super().__init__()
         object.__setattr__(self, "_owner", owner)
 
-    def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def capture(self, x: torch.Tensor) -> None:
+        """The call of reference models/model_wrapper.py:58: the transformer is run for the hook's capture only and its
+        output is discarded -- so the last block stops after its attention."""
+        self.forward(x, _need_hidden=False)
+
+    def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None, _need_hidden: bool = True) -> torch.Tensor:
         own = self._owner
         causal = False
         if attn_mask is not None:
@@ -89,7 +94,7 @@ class _TextTransformer(_Bag):
         attn_mod = self.resblocks[-1].attn
         user_hooks = len(attn_mod._forward_hooks) > 0
         intended = own.attn_semantics == "intended"
-        r = own._text.forward(x, causal=causal, want_hidden=True, want_heads=user_hooks and intended,
+        r = own._text.forward(x, causal=causal, want_hidden=_need_hidden, want_heads=user_hooks and intended,
                               want_mean=intended, want_attn_out=not intended)
         if intended:
             own.attention_maps.append(r["attn_mean"])               # [n, T, T]

@@ -160,7 +160,7 @@ class FullModel(nn.Module):
 
         # pass 1: only for the attention capture (model_wrapper.py:57-62)
         clip.reset()
-        clip.model.transformer(engine.build_prompts(ctx, tok))
+        clip.model.transformer.capture(engine.build_prompts(ctx, tok))
         attn_map = clip.get_attention_map()
         if attn_map.dim() == 2:
             attn_map = attn_map.unsqueeze(1)  # per sample [1,D] -> [1,1,D] in the reference (:60-61)
@@ -211,7 +211,7 @@ class FullModel(nn.Module):
             image_feat, side = self._image_features_begin(images)
             ctx_c, tok = pl.stacked_context().detach(), pl.stacked_tokens()
             clip.reset()
-            clip.model.transformer(engine.build_prompts(ctx_c, tok))
+            clip.model.transformer.capture(engine.build_prompts(ctx_c, tok))
             attn_map = clip.get_attention_map()
             if attn_map.dim() == 2:
                 attn_map = attn_map.unsqueeze(1)

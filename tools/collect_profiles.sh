@@ -2,7 +2,7 @@
 # Collects the round's profile set on the GPU box (run through gpurun from the repo root):
 #   tools/collect_profiles.sh <tag>     -> gpurun_out/prof_<tag>/..., summaries copied by hand into profiles/
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
