@@ -107,6 +107,19 @@ __global__ __launch_bounds__(512, (NKT % 2) ? 6 : 1) void attn_kernel(AttnArgs a
   const int64_t ld = 3 * (int64_t)D;
   const int qcol = head * 64, kcol = D + head * 64, vcol = 2 * D + head * 64;
 
+#ifdef ATTN_STAMP
+  // diagnostic build: 10-ns stamps of this workgroup's phases + where it ran (never in the library build)
+  auto stamp = [&](int slot) {
+    if (a.stamps != nullptr && tid == 0) a.stamps[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+  };
+  if (a.stamps != nullptr && tid == 0) {
+    unsigned hw_id, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    a.stamps[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | hw_id;
+  }
+  stamp(0);
+#endif
   // ---- Q fragments of every q-tile this wave owns, issued BEFORE the K/V staging so their latency
   // overlaps it.  B[k = d = 32*s + 8*g + j][col = q]; queries past T are clamped (never stored).
   constexpr int QT_MAX = (NKT + 7) / 8;  // 16-query tiles per wave (8 waves)
@@ -171,7 +184,13 @@ __global__ __launch_bounds__(512, (NKT % 2) ? 6 : 1) void attn_kernel(AttnArgs a
       }
     }
   }
+#ifdef ATTN_STAMP
+  stamp(1);  // thread 0's own loads have landed and its LDS writes are issued
+#endif
   __syncthreads();
+#ifdef ATTN_STAMP
+  stamp(2);  // K/V of the head staged
+#endif
 
 #pragma unroll
   for (int t = 0; t < QT_MAX; ++t) {
@@ -287,7 +306,16 @@ __global__ __launch_bounds__(512, (NKT % 2) ? 6 : 1) void attn_kernel(AttnArgs a
     // ---- store: lane holds O[q = qi][d = 16*g + 4*dt + e]
     if (!SPLIT && a.out_q != nullptr) store_o_mx8(a, oc, inv, row0 + qi, head, g, qi < T);  // (kernel-uniform branch)
     else if (qi < T) store_o_bf16<SPLIT>(a, oc, inv, row0 + qi, head, g);
+#ifdef ATTN_STAMP
+    stamp(3 + t);  // wave 0: its q-tile t done (stores issued)
+#endif
   }
+#ifdef ATTN_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stamp(5);  // wave 0's stores complete
+  __syncthreads();
+  stamp(6);  // all waves done
+#endif
 }
 
 // ---- long sequences (T > 256, e.g. ViT-L/14@336: 577 tokens): the same transposed products, flash style.

@@ -119,6 +119,7 @@ struct AttnArgs {
   uint8_t* out_q = nullptr;
   uint8_t* out_q_scale = nullptr;
   int64_t out_m_pad = 0;
+  unsigned long long* stamps = nullptr;  // diagnostic builds only (-DATTN_STAMP, tools/): [workgroup][8] s_memrealtime stamps
 };
 hipError_t launch_attention(const AttnArgs& a, bool split, hipStream_t s);
 

@@ -11,9 +11,10 @@ def is_distributed() -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
-def all_gather_rows(x: torch.Tensor, group=None) -> torch.Tensor:
-    """[B_local, E] on every rank -> [world * B_local, E], rank-major rows.  Identity at world size 1."""
-    if not is_distributed():
+def all_gather_rows(x: torch.Tensor, group=None, force: bool = False) -> torch.Tensor:
+    """[B_local, E] on every rank -> [world * B_local, E], rank-major rows.  Identity at world size 1 (`force=True`
+    still issues the collective on an initialised group of one rank: the RCCL call path on a 1-GPU box)."""
+    if not (is_distributed() or (force and dist.is_available() and dist.is_initialized())):
         return x
     x = x.contiguous()
     world = dist.get_world_size(group)

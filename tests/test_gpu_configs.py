@@ -381,6 +381,39 @@ def test_two_ranks_sharded_train_step_equals_single(tmp_path):
     assert r.returncode == 0 and r.stdout.count("ok") == 2, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+_NCCL_ONE_RANK = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import tap_clip_amd
+from tap_clip_amd.dist import all_gather_rows
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))      # what bench.py does for N > 1
+assert dist.get_backend() == "nccl"
+x = torch.nn.functional.normalize(torch.randn(256, 512, device="cuda"), dim=-1)
+y = all_gather_rows(x, force=True)                                     # dist.all_gather_into_tensor over RCCL
+lab = torch.arange(256, device="cuda")
+assert y.shape == (256, 512) and torch.equal(y, x) and torch.equal(all_gather_rows(lab, force=True), lab)
+t = torch.tensor([1.5], dtype=torch.float64, device="cuda")
+dist.all_reduce(t, op=dist.ReduceOp.MAX)                               # bench.py's max-over-ranks timing
+assert float(t) == 1.5
+dist.barrier(); dist.destroy_process_group()
+print("nccl ok")
+"""
+
+
+def test_rccl_call_path_on_one_rank(tmp_path):
+    """The `nccl` (= RCCL) branch of dist.py / bench.py with a group of ONE rank: a 1-GPU box cannot host two RCCL
+    ranks, but the initialisation, the device-tensor all_gather_into_tensor and the all_reduce run as they do at N > 1."""
+    script = tmp_path / "nccl1.py"
+    script.write_text(_NCCL_ONE_RANK % ROOT)
+    port = 29800 + os.getpid() % 90
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "nccl ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_literal_replay_refuses_to_train():
     g = golden("fullmodel_intended_tiny")
     model, images = _build_full("tiny", g, "intended", "bf16", collapse=False)
