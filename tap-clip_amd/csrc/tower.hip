@@ -12,6 +12,7 @@
 //   c_fc GEMM + bias + GELU -> bf16                     gemm*.hip EPI_BIAS_GELU_BF16
 //   c_proj GEMM + bias -> bf16 branch d                 gemm*.hip EPI_BIAS_BF16 (added by the next LN1 / the tail)
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -173,11 +174,37 @@ Workspace carve(const tapclip_tower* t, int64_t n_seq, int tokens, void* base) {
   return w;
 }
 
+// roctx ranges per kernel family (tracing), off by default: TAPCLIP_ROCTX=1 resolves
+// roctxRangePushA / roctxRangePop from libroctx64.so at first use, and every ProfScope -- one per kernel family launch
+// sequence -- becomes a named range that `rocprofv3 --marker-trace --kernel-trace` shows around its kernels.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char* e = getenv("TAPCLIP_ROCTX");
+    if (!e || !*e || *e == '0') return;
+    void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return;
+    push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+    pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+const Roctx& roctx() {
+  static const Roctx r;
+  return r;
+}
+const char* const kSlotNames[TAPCLIP_PROFILE_SLOTS] = {"tapclip:patch_embed", "tapclip:layernorm", "tapclip:gemm_qkv", "tapclip:attention",
+                                                       "tapclip:gemm_out_proj", "tapclip:gemm_fc_gelu", "tapclip:gemm_proj", "tapclip:pool_proj"};
+
 struct ProfScope {
   tapclip_tower* t;
   hipStream_t s;
   ProfRec* rec = nullptr;
+  bool range = false;
   ProfScope(tapclip_tower* tw, int slot, hipStream_t st) : t(tw), s(st) {
+    if (roctx().push && slot >= 0 && slot < TAPCLIP_PROFILE_SLOTS) range = roctx().push(kSlotNames[slot]) >= 0;
     if (!t->prof_on) return;
     if (t->prof_used == t->prof.size()) {
       ProfRec r;
@@ -197,6 +224,7 @@ struct ProfScope {
   }
   ~ProfScope() {
     if (rec) (void)hipEventRecord(rec->stop, s);
+    if (range) (void)roctx().pop();
   }
 };
 

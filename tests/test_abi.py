@@ -69,3 +69,96 @@ def test_missing_library_is_a_hard_error(monkeypatch):
         _lib.load()
     with pytest.raises(ImportError, match="no CPU fallback"):
         _lib.load("fp16")
+
+
+_SAN_SCRIPT = r"""
+import ctypes as C, sys
+sys.path.insert(0, %r)
+import tap_clip_amd
+from tap_clip_amd import _lib
+lib = C.CDLL(%r)
+for name, res, args in _lib.SYMBOLS:
+    fn = getattr(lib, name); fn.restype = res; fn.argtypes = args
+err = lambda: lib.tapclip_last_error().decode()
+# ---- handle lifecycle, config validation (every branch of tapclip_tower_create)
+good = dict(kind=0, width=768, layers=12, heads=12, mlp_dim=3072, embed_dim=512, image_size=224, patch=16, ctx_len=77, vocab=49408, act=0, precision=0)
+for bad in (dict(kind=7), dict(width=100), dict(heads=5), dict(mlp_dim=100), dict(layers=0), dict(embed_dim=4096), dict(precision=9), dict(act=3),
+            dict(image_size=225), dict(patch=0), dict(kind=1, ctx_len=0), dict(kind=1, precision=2), dict(precision=2, width=640, heads=10)):
+    h = C.c_void_p()
+    cfg = _lib.TowerCfg(**{**good, **bad})
+    assert lib.tapclip_tower_create(C.byref(cfg), C.byref(h)) == _lib.EINVAL, bad
+    assert err()
+assert lib.tapclip_tower_create(None, None) == _lib.EINVAL
+handles = []
+for kind, prec in ((0, 0), (0, 1), (0, 2), (1, 0), (1, 1)):
+    h = C.c_void_p()
+    cfg = _lib.TowerCfg(**{**good, "kind": kind, "precision": prec, **({"width": 512, "heads": 8, "mlp_dim": 2048} if kind else {})})
+    assert lib.tapclip_tower_create(C.byref(cfg), C.byref(h)) == 0, err()
+    handles.append((h, kind))
+for h, kind in handles:
+    assert lib.tapclip_tower_ready(h) == _lib.ESTATE and "missing" in err()
+    assert lib.tapclip_tower_workspace_bytes(h, 256, 197) > 0 and lib.tapclip_tower_workspace_bytes(h, 0, 197) == 0
+    if kind == 1:
+        assert lib.tapclip_text_backward_workspace_bytes(h, 65, 93) > lib.tapclip_tower_workspace_bytes(h, 65, 93)
+        assert lib.tapclip_text_saved_bytes(h, 65, 93) > 0
+    # weight bookkeeping: unknown key, wrong rank / shape (rejected before any device work), NULL arguments
+    shape = (C.c_int64 * 2)(3, 3)
+    dummy = (C.c_float * 16)()
+    assert lib.tapclip_tower_load_weight(h, b"no.such.key", dummy, shape, 2, None) == _lib.EINVAL and "unexpected key" in err()
+    key = b"transformer.resblocks.0.ln_1.weight"
+    assert lib.tapclip_tower_load_weight(h, key, dummy, shape, 2, None) == _lib.EINVAL and "size mismatch" in err()
+    assert lib.tapclip_tower_load_weight(h, key, None, shape, 2, None) == _lib.EINVAL
+    assert lib.tapclip_tower_load_weight(h, b"transformer.resblocks.11.mlp.c_proj.weight", dummy, shape, 2, None) == _lib.EINVAL
+    # entry points refuse the wrong tower kind / NULL / unloaded towers before touching the device
+    assert lib.tapclip_encode_image(h, None, 4, None, 0, None, 0, None) == _lib.EINVAL
+    assert lib.tapclip_text_forward(h, None, 4, 8, 0, None, None, None, None, None, 0, None) == _lib.EINVAL
+    rc = lib.tapclip_encode_image(h, dummy, 4, dummy, 0, dummy, 64, None)
+    assert rc in (_lib.EINVAL, _lib.ESTATE), rc                       # text tower: EINVAL; vision tower: weights missing
+    rc = lib.tapclip_text_forward(h, dummy, 4, 8, 0, dummy, None, None, None, dummy, 64, None)
+    assert rc in (_lib.EINVAL, _lib.ESTATE), rc
+    assert lib.tapclip_profile_enable(h, 1) == 0 and lib.tapclip_profile_enable(None, 1) == _lib.EINVAL
+    ms, n = (C.c_float * len(_lib.PROFILE_SLOTS))(), (C.c_int64 * len(_lib.PROFILE_SLOTS))()
+    assert lib.tapclip_profile_read(h, ms, n) == 0 and sum(n) == 0
+for h, _ in handles:
+    lib.tapclip_tower_destroy(h)
+lib.tapclip_tower_destroy(None)
+# ---- stand-alone ops: argument validation
+dummy = (C.c_float * 16)()
+assert lib.tapclip_logits(None, None, 1.0, 4, 4, 4, None, None) == _lib.EINVAL
+assert lib.tapclip_attribution(dummy, 0, 4, 4, 2, 1, dummy, None) == _lib.EINVAL
+assert lib.tapclip_build_prompts(dummy, dummy, dummy, 3, 2, 4, 77, 64, dummy, None) == _lib.EINVAL and "columns" in err()
+assert lib.tapclip_layernorm_f32(dummy, dummy, dummy, 4, 100, dummy, None) == _lib.EINVAL
+assert lib.tapclip_gemm_f32(dummy, dummy, None, 4, 100, 64, 0, dummy, dummy, 1 << 20, None) == _lib.EINVAL
+assert lib.tapclip_gemm_f32(dummy, dummy, None, 4, 128, 64, 0, dummy, dummy, 16, None) == _lib.EWORKSPACE
+assert lib.tapclip_gemm_scratch_bytes(100, 128, 64) > 0
+assert lib.tapclip_mx8_quantize(dummy, 4, 100, dummy, dummy, 8, None) == _lib.EINVAL
+assert lib.tapclip_mx8_gemm(dummy, dummy, 8, 8, dummy, dummy, None, 256, 256, 5, 0, dummy, None, None, None) == _lib.EINVAL
+assert lib.tapclip_mx8_gemm(dummy, dummy, 8, 8, dummy, dummy, None, 256, 256, 0, 0, None, None, None, None) == _lib.EINVAL
+ms6 = (C.c_float * 6)(0.5, 0.5, 0.5, 0.0, 0.2, 0.2)
+assert lib.tapclip_preprocess_u8(dummy, dummy, 2, 224, ms6, dummy, dummy, None) == _lib.EINVAL and "std" in err()
+assert lib.tapclip_preprocess_u8(dummy, dummy, 0, 224, ms6, dummy, dummy, None) == _lib.EINVAL
+assert lib.tapclip_abi_version() == 1
+print("sanitized host paths ok")
+"""
+
+
+def test_host_code_under_asan_and_ubsan(tmp_path):
+    """tower.hip's host half (handle lifecycle, every validation branch, weight bookkeeping, error strings) compiled with
+    -fsanitize=address,undefined (`make -C tap-clip_amd/csrc sanitize`) and driven through the C ABI without a GPU:
+    any heap error or undefined behaviour aborts the child (`-fno-sanitize-recover`).  GPU-side sanitizers are not
+    available on the pool, so this covers the host code only."""
+    import subprocess
+    import sys
+
+    csrc = os.path.join(ROOT, "tap-clip_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "sanitize"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rt = [l.split("=", 1)[1] for l in r.stdout.splitlines() if l.startswith("LD_PRELOAD=")][-1].strip()
+    assert os.path.exists(rt), rt
+    script = tmp_path / "san.py"
+    script.write_text(_SAN_SCRIPT % (ROOT, os.path.join(csrc, "libtapclip_san.so")))
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:verify_asan_link_order=0:halt_on_error=1",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and "sanitized host paths ok" in p.stdout, p.stdout[-3000:] + p.stderr[-6000:]
+    assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-6000:]
