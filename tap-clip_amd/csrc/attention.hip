@@ -57,13 +57,17 @@ __device__ __forceinline__ void store_o_bf16(const AttnArgs& a, const f32x4_t (&
       wh[2 * dt + 1] = pack_bf2(oc[dt][2] * inv, oc[dt][3] * inv);
     }
   }
-  uint4* dh = reinterpret_cast<uint4*>(a.out_hi + off);
-  dh[0] = make_uint4(wh[0], wh[1], wh[2], wh[3]);
-  dh[1] = make_uint4(wh[4], wh[5], wh[6], wh[7]);
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t* dh = reinterpret_cast<u32x4_t*>(a.out_hi + off);
+  // (non-temporal stores make this kernel faster ALONE -- 73.3 -> 67.6 us in tools/gemm_bench -- and slower in the
+  // tower, 79 -> 85 us with out_proj + 1.5 us behind it: there the output buffer is cache-resident from the previous
+  // block and its consumer reads it from the cache.  Plain stores.)
+  dh[0] = u32x4_t{wh[0], wh[1], wh[2], wh[3]};
+  dh[1] = u32x4_t{wh[4], wh[5], wh[6], wh[7]};
   if (SPLIT) {
-    uint4* dl = reinterpret_cast<uint4*>(a.out_lo + off);
-    dl[0] = make_uint4(wl[0], wl[1], wl[2], wl[3]);
-    dl[1] = make_uint4(wl[4], wl[5], wl[6], wl[7]);
+    u32x4_t* dl = reinterpret_cast<u32x4_t*>(a.out_lo + off);
+    dl[0] = u32x4_t{wl[0], wl[1], wl[2], wl[3]};
+    dl[1] = u32x4_t{wl[4], wl[5], wl[6], wl[7]};
   }
 }
 // MXFP8: the head's 64 columns are two 32-blocks, block b held by the lanes g = 2 b, 2 b + 1 of the row.  Called by

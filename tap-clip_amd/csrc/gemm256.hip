@@ -302,6 +302,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
       // i + 1 may be written right behind the (un-waited) reads of block i; the reads of block i are
       // waited for with a COUNTED lgkmcnt (NJ writes + R reads of block i + 1 stay in flight) just before
       // its global stores, and block i + 1's GELU/pack VALU work runs under block i's LDS latency.
+      // (the stores are non-temporal: QKV 165 -> 160 us, c_fc without GELU 228 -> 218 us in tools/gemm_bench; in the
+      // tower QKV -3.7 us, c_proj -6.3 us, the attention kernel behind QKV +1.8 us: -0.6 % on the step.  The same hint
+      // on the attention kernel's or the LayerNorm kernels' stores LOSES in the tower -- their outputs are re-used
+      // buffers that their consumers read from the cache -- so only these GEMM epilogues carry it.)
       constexpr int R = ROW_CHUNKS / 4;  // 16-B reads (= global stores) per lane per block
       auto tr_body = [&](auto act_tag) {
       constexpr int ACT = decltype(act_tag)::value;
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
           for (int t = 0; t < R; ++t) {
             const int64_t m = mrow0 + (i - 1) * 16 + rd_row[t];
-            if (full || m < g.M) *reinterpret_cast<u32x4_t*>(g.out_hi + m * g.ldo + ncol0 + rd_col[t]) = val[(i - 1) & 1][t];
+            if (full || m < g.M) __builtin_nontemporal_store(val[(i - 1) & 1][t], reinterpret_cast<u32x4_t*>(g.out_hi + m * g.ldo + ncol0 + rd_col[t]));
           }
         }
       }
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
       for (int t = 0; t < R; ++t) {
         const int64_t m = mrow0 + 7 * 16 + rd_row[t];
-        if (full || m < g.M) *reinterpret_cast<u32x4_t*>(g.out_hi + m * g.ldo + ncol0 + rd_col[t]) = val[1][t];
+        if (full || m < g.M) __builtin_nontemporal_store(val[1][t], reinterpret_cast<u32x4_t*>(g.out_hi + m * g.ldo + ncol0 + rd_col[t]));
       }
       };
       if (EPI != EPI_BIAS_GELU_BF16 || g.act == 0) tr_body(std::integral_constant<int, 0>{});
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
             pk[1] = pack_bf2(v0[2], v0[3]);
             pk[2] = pack_bf2(v1[0], v1[1]);
             pk[3] = pack_bf2(v1[2], v1[3]);
-            *reinterpret_cast<u32x4_t*>(orow + 32 * J) = pk;
+            __builtin_nontemporal_store(pk, reinterpret_cast<u32x4_t*>(orow + 32 * J));
           }
         }
       };
