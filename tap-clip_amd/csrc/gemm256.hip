@@ -303,9 +303,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
       // waited for with a COUNTED lgkmcnt (NJ writes + R reads of block i + 1 stay in flight) just before
       // its global stores, and block i + 1's GELU/pack VALU work runs under block i's LDS latency.
       // (the stores are non-temporal: QKV 165 -> 160 us, c_fc without GELU 228 -> 218 us in tools/gemm_bench; in the
-      // tower QKV -3.7 us, c_proj -6.3 us, the attention kernel behind QKV +1.8 us: -0.6 % on the step.  The same hint
-      // on the attention kernel's or the LayerNorm kernels' stores LOSES in the tower -- their outputs are re-used
-      // buffers that their consumers read from the cache -- so only these GEMM epilogues carry it.)
+      // tower, beside the non-temporal residual stream of layernorm.hip, -2.4 % on the step (QKV 181 -> 171, c_fc 277
+      // -> 268, c_proj 244 -> 237 us).  The same hint on the attention kernel's stores or on the LayerNorm kernels'
+      // 16-bit outputs LOSES in the tower -- re-used buffers that their consumers read from the cache -- as do
+      // non-temporal loads of q|k|v, of the branch tensors and of the images.)
       constexpr int R = ROW_CHUNKS / 4;  // 16-B reads (= global stores) per lane per block
       auto tr_body = [&](auto act_tag) {
       constexpr int ACT = decltype(act_tag)::value;
