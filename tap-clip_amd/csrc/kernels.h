@@ -75,7 +75,7 @@ hipError_t launch_gemm_mx8(const Mx8GemmArgs& a, int epilogue, hipStream_t s);
 // LayerNorm over rows; one wave per row.  out_hi/out_lo (bf16) or out_f32; x may alias out_f32.
 hipError_t launch_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta,
                             int64_t rows, int32_t d, bf16_t* out_hi, bf16_t* out_lo, float* out_f32,
-                            hipStream_t s);
+                            hipStream_t s, bool stream_x = false);
 
 // x += delta (bf16 hi [+ lo]) written back in fp32, then LayerNorm(x) -> bf16 hi [+ lo]
 hipError_t launch_add_layernorm(float* x, const bf16_t* delta_hi, const bf16_t* delta_lo, const float* gamma,
@@ -84,7 +84,7 @@ hipError_t launch_add_layernorm(float* x, const bf16_t* delta_hi, const bf16_t* 
 // add: 1 = x += d1 (written back); 2 = LayerNorm(x + d1), x NOT written back; 3 = x += d1 + d2 (written back)
 hipError_t launch_add_layernorm_ex(int add, float* x, const bf16_t* d1_hi, const bf16_t* d1_lo, const bf16_t* d2_hi,
                                    const bf16_t* d2_lo, const float* gamma, const float* beta, int64_t rows, int32_t d,
-                                   bf16_t* out_hi, bf16_t* out_lo, hipStream_t s);
+                                   bf16_t* out_hi, bf16_t* out_lo, hipStream_t s, bool stream_x = false);
 // LayerNorm with MXFP8 output: out_q [rows, d] e4m3 + out_sc [d/64][rows_pad][2]; add = 0 (none) or as above.
 // x16 != nullptr: the residual stream is 16-bit ([rows, d]) and x is ignored.
 hipError_t launch_layernorm_mx8(int add, float* x, bf16_t* x16, const bf16_t* d1_hi, const bf16_t* d2_hi, const float* gamma,

@@ -20,8 +20,9 @@ namespace {
 //      MXFP8 operand error and the LayerNorms are 20 % of the step
 //   2  "x24": the fp32 value rounded (nearest-even) to 16 significand bits and kept as two planes, x16 = its upper 16
 //      bits and x8 = the next 8: 3 bytes per element at 2^-17 relative rounding (2e-5 over the 24 roundings of ViT-B:
-//      a tenth of the IEEE-half operand error of the "fp16" mode, 1 % of bf16's).  The image tower's 16-bit modes use
-//      it: the LayerNorm kernels are HBM-bound (6 TB/s) and their bytes drop 14 -> 12 (LN1) and 8 -> 7 (LN2).
+//      a tenth of the IEEE-half operand error of the "fp16" mode, 1 % of bf16's).  The LayerNorm kernels are HBM-bound
+//      (6 TB/s) and their bytes drop 14 -> 12 (LN1) and 8 -> 7 (LN2): -1.5 % on the step.  OPT-IN (TAPCLIP_X24=1,
+//      tower.hip): a tower on this layout returns wrong rows when a second stream keeps the GPU busy beside it.
 // PRE (XF = 2, ADD = 0): the row is first read as fp32 from x, normalised with (gamma_pre, beta_pre) -- ln_pre of the
 //   image tower -- and THAT is the residual row, written in the XF format; then the LayerNorm proper (block 0's ln_1)
 //   runs on it: one pass over the patch embeddings instead of an in-place fp32 ln_pre followed by a second kernel.
@@ -41,11 +42,8 @@ __device__ __forceinline__ void x24_store(bf16_t* hi, uint8_t* lo, const float4&
 #endif
 }
 __device__ __forceinline__ float4 x24_load(const bf16_t* hi, const uint8_t* lo) {
-  // The planes are streamed NON-TEMPORALLY, loads and stores: a row of the residual stream is touched once per
-  // LayerNorm and not again for ~250 us and ~1 GB of other traffic, so keeping it out of the L2 / Infinity Cache leaves
-  // them to the tensors the NEXT kernel reads (this kernel's 16-bit output, the GEMM outputs).  Measured on the tower
-  // (bench.py, same box, interleaved): 11.53 -> 11.19 ms per step, QKV 172 -> 160 us, c_fc 263 -> 252 us, attention
-  // 79 -> 76 us -- the LayerNorm kernels themselves do not change.  Stores alone: nothing; loads alone: -1.9 %.
+  // The planes are streamed non-temporally like the fp32 stream (NTX below): 11.53 -> 11.19 ms per step with the planes
+  // (stores alone: nothing; loads alone: -1.9 %).
 #ifndef TAPCLIP_X24_PLAIN
   const ln_u32x2_t hh = __builtin_nontemporal_load(reinterpret_cast<const ln_u32x2_t*>(hi));
   const uint2 h = make_uint2(hh[0], hh[1]);
@@ -58,7 +56,13 @@ __device__ __forceinline__ float4 x24_load(const bf16_t* hi, const uint8_t* lo) 
                      __uint_as_float((h.y << 16) | ((l >> 8) & 0xFF00u)), __uint_as_float((h.y & 0xFFFF0000u) | ((l >> 16) & 0xFF00u)));
 }
 
-template <int MODE, int NV, int ADD, int XF = 0, bool PRE = false>  // NV float4 per lane: d = 256 * NV
+// NTX (XF = 0): the fp32 residual row is loaded and stored NON-TEMPORALLY -- the image tower's 16-bit modes.  A row of the
+//   residual stream is touched once per LayerNorm and not again for ~250 us and ~1 GB of other traffic, so keeping it
+//   out of the L2 / Infinity Cache leaves them to the tensors the NEXT kernel reads (this kernel's 16-bit output, the
+//   GEMM outputs): 11.98 -> 11.59 ms per step (bench.py, same box, interleaved), QKV 177 -> 169 us, c_fc 276 -> 263 us,
+//   attention 82 -> 77 us, the LayerNorm kernels themselves unchanged.  (The text tower's stream is 12 MB and lives in
+//   the caches anyway.)
+template <int MODE, int NV, int ADD, int XF = 0, bool PRE = false, bool NTX = false>  // NV float4 per lane: d = 256 * NV
 __global__ __launch_bounds__(256) void ln_vec_kernel(float* __restrict__ x, int64_t ldx, bf16_t* __restrict__ x16, uint8_t* __restrict__ x8,
                                                      const bf16_t* __restrict__ d_hi, const bf16_t* __restrict__ d_lo,
                                                      const bf16_t* __restrict__ e_hi, const bf16_t* __restrict__ e_lo,
@@ -117,6 +121,10 @@ __global__ __launch_bounds__(256) void ln_vec_kernel(float* __restrict__ x, int6
       v[j] = make_float4(bf2f((bf16_t)(h.x & 0xFFFF)), bf2f((bf16_t)(h.x >> 16)), bf2f((bf16_t)(h.y & 0xFFFF)), bf2f((bf16_t)(h.y >> 16)));
     } else if (XF == 2) {
       v[j] = x24_load(x16 + row * d + c, x8 + row * d + c);
+    } else if (NTX) {
+      typedef float lf32x4_t __attribute__((ext_vector_type(4)));
+      const lf32x4_t t4 = __builtin_nontemporal_load(reinterpret_cast<const lf32x4_t*>(xr + c));
+      v[j] = make_float4(t4[0], t4[1], t4[2], t4[3]);
     } else {
       v[j] = *reinterpret_cast<const float4*>(xr + c);
     }
@@ -135,7 +143,10 @@ __global__ __launch_bounds__(256) void ln_vec_kernel(float* __restrict__ x, int6
       if (ADD != 2) {
         if (XH) __builtin_nontemporal_store((ln_u32x2_t{pack_bf2(v[j].x, v[j].y), pack_bf2(v[j].z, v[j].w)}), reinterpret_cast<ln_u32x2_t*>(x16 + row * d + c));
         else if (XF == 2) x24_store(x16 + row * d + c, x8 + row * d + c, v[j]);
-        else *reinterpret_cast<float4*>(xr + c) = v[j];
+        else if (NTX) {
+          typedef float lf32x4_t __attribute__((ext_vector_type(4)));
+          __builtin_nontemporal_store((lf32x4_t{v[j].x, v[j].y, v[j].z, v[j].w}), reinterpret_cast<lf32x4_t*>(xr + c));
+        } else *reinterpret_cast<float4*>(xr + c) = v[j];
       }
     }
     s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
@@ -244,7 +255,7 @@ __global__ __launch_bounds__(256) void ln_generic_kernel(float* __restrict__ x, 
 template <int MODE, int ADD>
 hipError_t launch_mode(float* x, int64_t ldx, const bf16_t* dh, const bf16_t* dl, const bf16_t* eh, const bf16_t* el, const float* gamma,
                        const float* beta, int64_t rows, int32_t d, bf16_t* hi, bf16_t* lo, float* f32, hipStream_t s, uint8_t* q = nullptr,
-                       uint8_t* qs = nullptr, int64_t rows_pad = 0, bf16_t* x16 = nullptr) {
+                       uint8_t* qs = nullptr, int64_t rows_pad = 0, bf16_t* x16 = nullptr, bool ntx = false) {
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   if (x16 != nullptr) {  // 16-bit residual stream: MXFP8 output only
     if constexpr (MODE == 3) {
@@ -259,6 +270,17 @@ hipError_t launch_mode(float* x, int64_t ldx, const bf16_t* dh, const bf16_t* dl
     } else {
       return hipErrorInvalidValue;
     }
+  }
+  if (ntx && MODE == 0 && d % 256 == 0 && d / 256 <= 4 && ldx % 4 == 0) {
+    if constexpr (MODE == 0) {
+      switch (d / 256) {
+        case 1: hipLaunchKernelGGL((ln_vec_kernel<0, 1, ADD, 0, false, true>), grid, block, 0, s, x, ldx, nullptr, nullptr, dh, dl, eh, el, nullptr, nullptr, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+        case 2: hipLaunchKernelGGL((ln_vec_kernel<0, 2, ADD, 0, false, true>), grid, block, 0, s, x, ldx, nullptr, nullptr, dh, dl, eh, el, nullptr, nullptr, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+        case 3: hipLaunchKernelGGL((ln_vec_kernel<0, 3, ADD, 0, false, true>), grid, block, 0, s, x, ldx, nullptr, nullptr, dh, dl, eh, el, nullptr, nullptr, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+        default: hipLaunchKernelGGL((ln_vec_kernel<0, 4, ADD, 0, false, true>), grid, block, 0, s, x, ldx, nullptr, nullptr, dh, dl, eh, el, nullptr, nullptr, gamma, beta, rows, d, hi, lo, f32, q, qs, rows_pad); break;
+      }
+    }
+    return hipGetLastError();
   }
   if (d % 256 == 0 && d / 256 <= 4 && ldx % 4 == 0) {
     switch (d / 256) {
@@ -277,12 +299,12 @@ hipError_t launch_mode(float* x, int64_t ldx, const bf16_t* dh, const bf16_t* dl
 template <int MODE>
 hipError_t launch_add_mode(int add, float* x, const bf16_t* dh, const bf16_t* dl, const bf16_t* eh, const bf16_t* el, const float* gamma,
                            const float* beta, int64_t rows, int32_t d, bf16_t* hi, bf16_t* lo, hipStream_t s, uint8_t* q = nullptr,
-                           uint8_t* qs = nullptr, int64_t rows_pad = 0, bf16_t* x16 = nullptr) {
+                           uint8_t* qs = nullptr, int64_t rows_pad = 0, bf16_t* x16 = nullptr, bool ntx = false) {
   switch (add) {
-    case 0: return launch_mode<MODE, 0>(x, d, nullptr, nullptr, nullptr, nullptr, gamma, beta, rows, d, hi, lo, nullptr, s, q, qs, rows_pad, x16);
-    case 1: return launch_mode<MODE, 1>(x, d, dh, dl, nullptr, nullptr, gamma, beta, rows, d, hi, lo, nullptr, s, q, qs, rows_pad, x16);
-    case 2: return launch_mode<MODE, 2>(x, d, dh, dl, nullptr, nullptr, gamma, beta, rows, d, hi, lo, nullptr, s, q, qs, rows_pad, x16);
-    case 3: return launch_mode<MODE, 3>(x, d, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, nullptr, s, q, qs, rows_pad, x16);
+    case 0: return launch_mode<MODE, 0>(x, d, nullptr, nullptr, nullptr, nullptr, gamma, beta, rows, d, hi, lo, nullptr, s, q, qs, rows_pad, x16, ntx);
+    case 1: return launch_mode<MODE, 1>(x, d, dh, dl, nullptr, nullptr, gamma, beta, rows, d, hi, lo, nullptr, s, q, qs, rows_pad, x16, ntx);
+    case 2: return launch_mode<MODE, 2>(x, d, dh, dl, nullptr, nullptr, gamma, beta, rows, d, hi, lo, nullptr, s, q, qs, rows_pad, x16, ntx);
+    case 3: return launch_mode<MODE, 3>(x, d, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, nullptr, s, q, qs, rows_pad, x16, ntx);
     default: return hipErrorInvalidValue;
   }
 }
@@ -290,27 +312,27 @@ hipError_t launch_add_mode(int add, float* x, const bf16_t* dh, const bf16_t* dl
 }  // namespace
 
 hipError_t launch_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, int64_t rows,
-                            int32_t d, bf16_t* out_hi, bf16_t* out_lo, float* out_f32, hipStream_t s) {
+                            int32_t d, bf16_t* out_hi, bf16_t* out_lo, float* out_f32, hipStream_t s, bool stream_x) {
   if (rows <= 0 || d <= 0 || d % 64 != 0) return hipErrorInvalidValue;
   float* xm = const_cast<float*>(x);  // not written without ADD
   if (out_f32 != nullptr) return launch_mode<2, 0>(xm, ldx, nullptr, nullptr, nullptr, nullptr, gamma, beta, rows, d, nullptr, nullptr, out_f32, s);
   if (out_lo != nullptr) return launch_mode<1, 0>(xm, ldx, nullptr, nullptr, nullptr, nullptr, gamma, beta, rows, d, out_hi, out_lo, nullptr, s);
-  return launch_mode<0, 0>(xm, ldx, nullptr, nullptr, nullptr, nullptr, gamma, beta, rows, d, out_hi, nullptr, nullptr, s);
+  return launch_mode<0, 0>(xm, ldx, nullptr, nullptr, nullptr, nullptr, gamma, beta, rows, d, out_hi, nullptr, nullptr, s, nullptr, nullptr, 0, nullptr, stream_x);
 }
 
 hipError_t launch_add_layernorm(float* x, const bf16_t* delta_hi, const bf16_t* delta_lo, const float* gamma,
                                 const float* beta, int64_t rows, int32_t d, bf16_t* out_hi, bf16_t* out_lo,
                                 hipStream_t s) {
-  return launch_add_layernorm_ex(1, x, delta_hi, delta_lo, nullptr, nullptr, gamma, beta, rows, d, out_hi, out_lo, s);
+  return launch_add_layernorm_ex(1, x, delta_hi, delta_lo, nullptr, nullptr, gamma, beta, rows, d, out_hi, out_lo, s, false);
 }
 
 // add: 1 = x += d1 (written back); 2 = normalise x + d1 without writing x back; 3 = x += d1 + d2 (written back)
 hipError_t launch_add_layernorm_ex(int add, float* x, const bf16_t* d1_hi, const bf16_t* d1_lo, const bf16_t* d2_hi,
                                    const bf16_t* d2_lo, const float* gamma, const float* beta, int64_t rows, int32_t d,
-                                   bf16_t* out_hi, bf16_t* out_lo, hipStream_t s) {
+                                   bf16_t* out_hi, bf16_t* out_lo, hipStream_t s, bool stream_x) {
   if (rows <= 0 || d <= 0 || d % 64 != 0 || add < 1 || add > 3 || d1_hi == nullptr || (add == 3 && d2_hi == nullptr)) return hipErrorInvalidValue;
   if (out_lo != nullptr) return launch_add_mode<1>(add, x, d1_hi, d1_lo, d2_hi, d2_lo, gamma, beta, rows, d, out_hi, out_lo, s);
-  return launch_add_mode<0>(add, x, d1_hi, nullptr, d2_hi, nullptr, gamma, beta, rows, d, out_hi, nullptr, s);
+  return launch_add_mode<0>(add, x, d1_hi, nullptr, d2_hi, nullptr, gamma, beta, rows, d, out_hi, nullptr, s, nullptr, nullptr, 0, nullptr, stream_x);
 }
 
 // ---- 24-bit residual stream (XF = 2; the image tower's bf16 / IEEE-half modes).  bf16 output only.
