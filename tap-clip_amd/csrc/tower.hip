@@ -288,6 +288,28 @@ std::string shape_str(const int64_t* shape, int ndim) {
   return s + "]";
 }
 
+// m-tiles per group of the persistent GEMM's XCD-aware tile order, per kernel family (slot 2 QKV, 4 out_proj, 5 c_fc,
+// 6 c_proj).  Measured in the tower at ViT-B/16, batch 256 (bench.py, same box): QKV 159 -> 154-157 us at 6; out_proj
+// 69 us at 8 and 76 us at 7, 9 or 10; c_fc 251 -> 245 us at 2-4; c_proj 227 -> 218-221 us at 1-4: -1 % on the step
+// against 8 everywhere (ViT-L/14@336, batch 128: QKV 416 -> 397, c_proj 556 -> 538 us, c_fc 630 us at 3, 6 and 8 but 720 us
+// at 2: hence 3).  TAPCLIP_GM="q,o,f,p" overrides (experiments).
+int group_m_for(int slot) {
+  static int gm[4] = {6, 8, 3, 2};
+  static const bool init = [] {
+    const char* e = getenv("TAPCLIP_GM");
+    if (e) sscanf(e, "%d,%d,%d,%d", &gm[0], &gm[1], &gm[2], &gm[3]);
+    return true;
+  }();
+  (void)init;
+  switch (slot) {
+    case 2: return gm[0];
+    case 4: return gm[1];
+    case 5: return gm[2];
+    case 6: return gm[3];
+    default: return 8;
+  }
+}
+
 int dbg_sync_mask() {
   static const int m = [] { const char* e = getenv("TAPCLIP_DEBUG_SYNC"); return e ? atoi(e) : 0; }();
   return m;
@@ -312,6 +334,7 @@ int gemm(tapclip_tower* t, int slot, int epi, const bf16_t* a_hi, const bf16_t* 
   g.out_hi = o_hi; g.out_lo = o_lo; g.out_f32 = o_f32; g.ldo = ldo;
   g.add_table = add_table; g.rows_per_group = rows_per_group;
   g.act = t->cfg.act;
+  g.group_m = group_m_for(slot);
   ProfScope ps(t, slot, s);
   HIP_TRY(launch_gemm(g, epi, t->split, s));
   DBG_SYNC(2, s);
