@@ -310,6 +310,23 @@ int group_m_for(int slot) {
   }
 }
 
+int group_m_mx8_for(int slot) {  // the same for the MXFP8 GEMM (TAPCLIP_GM8="q,o,f,p")
+  static int gm[4] = {8, 8, 8, 8};
+  static const bool init = [] {
+    const char* e = getenv("TAPCLIP_GM8");
+    if (e) sscanf(e, "%d,%d,%d,%d", &gm[0], &gm[1], &gm[2], &gm[3]);
+    return true;
+  }();
+  (void)init;
+  switch (slot) {
+    case 2: return gm[0];
+    case 4: return gm[1];
+    case 5: return gm[2];
+    case 6: return gm[3];
+    default: return 8;
+  }
+}
+
 int dbg_sync_mask() {
   static const int m = [] { const char* e = getenv("TAPCLIP_DEBUG_SYNC"); return e ? atoi(e) : 0; }();
   return m;
@@ -349,6 +366,7 @@ int gemm_mx8(tapclip_tower* t, int slot, int epi, const uint8_t* a_q, const uint
   g.M = M; g.N = N; g.K = K;
   g.out_bf16 = o_bf16; g.out_q = o_q; g.out_q_scale = o_s; g.out_m_pad = m_pad; g.ldo = N;
   g.act = t->cfg.act;
+  g.group_m = group_m_mx8_for(slot);
   ProfScope ps(t, slot, s);
   HIP_TRY(launch_gemm_mx8(g, epi, s));
   return TAPCLIP_OK;
