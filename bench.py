@@ -250,10 +250,10 @@ def main():
             # fp32 residual (the default): ln_pre (fp32 -> fp32: 8 B/element), LN1 of block 0 (fp32 -> bf16: 6),
             # LN2 of blocks 0..L-2 (read x + one branch, write the 16-bit output only: 8), LN2 of the last block (also
             # writes x: 12), LN1 of blocks 1..L-1 (read x + two branches, write x + output: 14).
-            # 24-bit residual planes (TAPCLIP_X24=1, layernorm.hip XF = 2): ln_pre + LN1 of block 0 in one kernel
+            # 24-bit residual planes (default; TAPCLIP_X24=0 for fp32; layernorm.hip XF = 2): ln_pre + LN1 of block 0 in one kernel
             # (read fp32, write planes + output: 9), LN2 7 / 10, LN1 12.  (fp8: 16-bit stream, 1.03-B outputs; not modelled.)
             L = cfg.vision.layers
-            x24 = args.precision in ("bf16", "fp16") and cfg.vision.width % 256 == 0 and bool(os.environ.get("TAPCLIP_X24"))
+            x24 = args.precision in ("bf16", "fp16") and cfg.vision.width % 256 == 0 and os.environ.get("TAPCLIP_X24", "1") != "0"
             per_elt = (9 + (L - 1) * 7 + 10 + (L - 1) * 12) if x24 else (8 + 6 + (L - 1) * 8 + 12 + (L - 1) * 14)
             ln_bytes = rd * per_elt
             result["layernorm_hbm"] = {"achieved_GBps": round(ln_bytes * args.steps / (ln[0] * 1e-3) / 1e9, 1), "peak_GBps": HBM_PEAK_GBS,

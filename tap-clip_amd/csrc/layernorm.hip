@@ -2,6 +2,8 @@
 // Replaces the ln_pre / ln_1 / ln_2 / ln_post nn.LayerNorm calls inside open_clip's blocks
 // (SURVEY.md section 2.1 K2).  HBM-bound: reads the fp32 residual row once, writes the bf16 GEMM
 // operand (hi, and lo for bf16x3) or fp32 (ln_pre in place, unit API).
+// (no packed-fp32 ops in this file: a LayerNorm runs beside the other tower's GEMMs -- common.h)
+#define TAPCLIP_TU_NO_PK_F32
 #include "common.h"
 #include "kernels.h"
 
@@ -73,8 +75,9 @@ __global__ __launch_bounds__(256) void ln_vec_kernel(float* __restrict__ x, int6
                                                      uint8_t* out_q, uint8_t* out_sc, int64_t rows_pad) {
   static_assert(!PRE || (XF == 2 && ADD == 0), "PRE: fp32 source -> x24 residual");
   constexpr bool XH = XF == 1;
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int tid = (int)__builtin_amdgcn_workitem_id_x();  // (threadIdx / blockIdx are device-library calls that do not
+  const int lane = tid & 63;                              //  inline into a function without packed-fp32 ops)
+  const int64_t row = (int64_t)__builtin_amdgcn_workgroup_id_x() * 4 + (tid >> 6);
   if (row >= rows) return;
   float* xr = (XF != 0 && !PRE) ? nullptr : x + row * ldx;
   float4 v[NV];
@@ -206,8 +209,9 @@ __global__ __launch_bounds__(256) void ln_generic_kernel(float* __restrict__ x, 
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, int64_t rows, int d,
                                                          bf16_t* out_hi, bf16_t* out_lo, float* out_f32) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int tid = (int)__builtin_amdgcn_workitem_id_x();  // (threadIdx / blockIdx are device-library calls that do not
+  const int lane = tid & 63;                              //  inline into a function without packed-fp32 ops)
+  const int64_t row = (int64_t)__builtin_amdgcn_workgroup_id_x() * 4 + (tid >> 6);
   if (row >= rows) return;
   float* xr = x + row * ldx;
   auto val = [&](int c) {  // the row element with its pending branches (same order of additions as ln_vec_kernel)
@@ -378,7 +382,7 @@ hipError_t launch_layernorm_x24(int add, int pre, const float* src_f32, int64_t 
 namespace {
 __global__ void gather_cls24_kernel(const bf16_t* __restrict__ xhi, const uint8_t* __restrict__ xlo, const bf16_t* __restrict__ delta,
                                     int tokens, int D, int64_t total, float* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = (int64_t)__builtin_amdgcn_workgroup_id_x() * 256 + __builtin_amdgcn_workitem_id_x();
   if (i >= total) return;
   const int64_t b = i / D;
   const int64_t src = b * tokens * (int64_t)D + (i - b * D);
@@ -404,3 +408,5 @@ hipError_t launch_layernorm_mx8(int add, float* x, bf16_t* x16, const bf16_t* d1
 }
 
 }  // namespace tapclip
+
+TAPCLIP_TU_NO_PK_F32_END

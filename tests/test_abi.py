@@ -162,3 +162,56 @@ def test_host_code_under_asan_and_ubsan(tmp_path):
     p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0 and "sanitized host paths ok" in p.stdout, p.stdout[-3000:] + p.stderr[-6000:]
     assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-6000:]
+
+
+# ---- the shipped gfx950 code holds no packed-fp32 op in the encoding that MI355X gets wrong beside a busy neighbour
+def _gfx950_code_objects(path, tmp_path):
+    """The gfx950 code objects embedded in a hipcc-built library: every clang offload bundle of its .hip_fatbin."""
+    import struct
+    blob = open(path, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    out, pos = [], blob.find(magic)
+    while pos >= 0:
+        n, = struct.unpack_from("<Q", blob, pos + len(magic))
+        q = pos + len(magic) + 8
+        for _ in range(n):
+            off, size, tlen = struct.unpack_from("<QQQ", blob, q)
+            triple = blob[q + 24:q + 24 + tlen].decode()
+            q += 24 + tlen
+            if "gfx950" in triple and size:
+                f = tmp_path / f"{os.path.basename(path)}.{len(out)}.co"
+                f.write_bytes(blob[pos + off:pos + off + size])
+                out.append(str(f))
+        pos = blob.find(magic, pos + len(magic))
+    return out
+
+
+_PK_F32 = re.compile(r"\bv_pk_(?:fma|mul|add)_f32\b.*\bop_sel:\[0,1")
+
+
+@pytest.mark.parametrize("variant", ["bf16", "fp16"])
+def test_no_unsafe_packed_fp32_encodings(variant, tmp_path):
+    """MI355X returns wrong lanes 48..63 for v_pk_{fma,mul,add}_f32 with op_sel = [0,1,...] (low result = src0.lo with
+    src1.HI) while another kernel's waves run LDS-fed MFMAs on the same CU -- measured by tools/probes/pk_opsel_table.hip,
+    table in profiles/r02_pk_opsel_table.txt; hipcc emits that encoding by itself (csrc/common.h TAPCLIP_TU_NO_PK_F32).
+    The towers run side by side on two streams, so no kernel of the library may contain it."""
+    import shutil, subprocess
+    objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not found")
+    path = _lib.LIB_PATH if variant == "bf16" else _lib.LIB_PATH_FP16
+    cos = _gfx950_code_objects(path, tmp_path)
+    assert len(cos) >= 8, f"expected a gfx950 code object per kernel file in {path}, found {len(cos)}"
+    n_pk, bad = 0, []
+    for co in cos:
+        txt = subprocess.run([objdump, "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
+        kernel = "?"
+        for line in txt.splitlines():
+            if line.endswith(">:"):
+                kernel = line.split("<")[-1][:-2]
+            elif "v_pk_" in line:
+                n_pk += "_f32" in line
+                if _PK_F32.search(line):
+                    bad.append(f"{kernel[:90]}: {line.strip()}")
+    assert n_pk > 1000, "the disassembly did not show the GEMM epilogues' packed ops: is the check still looking at the kernels?"
+    assert not bad, f"{len(bad)} packed-fp32 ops with op_sel = [0,1,...]:\n" + "\n".join(bad[:10])

@@ -429,9 +429,10 @@ def test_literal_replay_refuses_to_train():
                                                   ("ViT-B-16", 64, "fp8")])
 def test_image_tower_is_bit_stable_beside_a_busy_second_stream(eng, name, batch, precision):
     """`encode_image` on a side stream while the main stream runs (a) the split-bf16 text tower, (b) torch matmuls:
-    every run must equal the solo run bit for bit.  (Round 2 found a residual-stream layout -- 24-bit planes,
-    tower.hip TAPCLIP_X24 -- whose results went wrong 19 times in 20 under exactly this load while every solo test
-    passed; the layout is off by default and this test guards whatever replaces it.)"""
+    every run must equal the solo run bit for bit.  (Round 2: the tower on 24-bit residual planes went wrong 19 times
+    in 20 under exactly this load while every solo test passed -- its LayerNorms held v_pk_fma_f32 with op_sel:[0,1,0],
+    which MI355X gets wrong in lanes 48..63 beside another kernel's MFMAs; csrc/common.h TAPCLIP_TU_NO_PK_F32,
+    tests/test_abi.py::test_no_unsafe_packed_fp32_encodings, test_packed_fp32_probe_* below.)"""
     cfg = configs.get_config(name)
     sd = synth.make_state_dict(cfg, seed=2)
     images = synth.make_images(batch, cfg, 0).to(DEV)
@@ -463,3 +464,59 @@ def test_image_tower_is_bit_stable_beside_a_busy_second_stream(eng, name, batch,
             torch.cuda.synchronize()
             differ += int(not torch.equal(e, base))
         assert differ == 0, f"{name} batch {batch} {precision} beside {label}: {differ}/10 runs differ from the solo run"
+
+
+def test_text_tower_is_bit_stable_beside_the_image_tower(eng):
+    """The other direction: the text tower (bf16 and split-bf16; its LayerNorms run beside the image tower's GEMMs in
+    FullModel(overlap_towers=True)) on the main stream while a side stream runs the image tower."""
+    cfg = configs.get_config("ViT-B-16")
+    sd = synth.make_state_dict(cfg, seed=4)
+    images = synth.make_images(64, cfg, 0).to(DEV)
+    ctx, tok = synth.make_prompts(65, 5, cfg, seed=1)
+    prompts = torch.cat([ctx, tok], 1).to(DEV)
+    tower = eng.VisionTower(cfg, sd, DEV, "bf16")
+    side = torch.cuda.Stream()
+    for precision in ("bf16", "bf16x3"):
+        text = eng.TextTower(cfg, sd, DEV, precision)
+        base = [t.clone() for t in text.forward(prompts, want_mean=True).values() if torch.is_tensor(t)]
+        torch.cuda.synchronize()
+        for it in range(10):
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                tower.encode_image(images, normalize=True)
+                tower.encode_image(images, normalize=True)
+            got = [t for t in text.forward(prompts, want_mean=True).values() if torch.is_tensor(t)]
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            for g, b in zip(got, base):
+                assert torch.equal(g, b), f"text tower ({precision}) beside the image tower, iteration {it}: {(g - b).abs().max().item():.3e}"
+
+
+def _pk_probe(tmp_path):
+    import shutil, subprocess
+    exe = os.path.join(ROOT, "tools", "probes", "pk_opsel_table")
+    if not os.path.exists(exe):
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        src = os.path.join(ROOT, "tools", "probes", "pk_opsel_table.hip")
+        if not (os.path.exists(hipcc) and os.path.exists(src)):
+            pytest.skip("tools/probes/pk_opsel_table is not built and cannot be built here")
+        exe = str(tmp_path / "pk_opsel_table")
+        subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-Wno-inline-asm", "-o", exe, src], check=True, capture_output=True)
+    out = subprocess.run([exe, "30"], capture_output=True, text=True, timeout=300, check=True).stdout
+    alone, beside = out.split("== beside")
+    return alone, beside
+
+
+def test_packed_fp32_probe_every_failing_encoding_is_one_the_library_check_rejects(tmp_path):
+    """tools/probes/pk_opsel_table: all 96 op_sel / op_sel_hi encodings of v_pk_{fma,mul,add}_f32 against scalar ops.
+    Alone none fails.  Beside a GEMM-like kernel on a second stream the op_sel = [0,1,...] ones fail (lanes 48..63):
+    that is the set tests/test_abi.py keeps out of the library -- if ANY other encoding ever fails here, that check is
+    no longer sufficient."""
+    alone, beside = _pk_probe(tmp_path)
+    assert "0 of 96 encodings returned wrong results" in alone, alone
+    bad = [l for l in beside.splitlines() if "UNSAFE" in l]
+    outside = [l for l in bad if "op_sel:[0,1" not in l]
+    assert not outside, "encodings outside op_sel = [0,1,...] failed:\n" + "\n".join(outside)
+    for l in bad:  # and only in the last 16-lane quad
+        q = [int(v) for v in l.split("quad:")[1].split()]
+        assert q[0] == q[1] == q[2] == 0, l
