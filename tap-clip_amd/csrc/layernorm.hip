@@ -23,8 +23,8 @@ namespace {
 //   2  "x24": the fp32 value rounded (nearest-even) to 16 significand bits and kept as two planes, x16 = its upper 16
 //      bits and x8 = the next 8: 3 bytes per element at 2^-17 relative rounding (2e-5 over the 24 roundings of ViT-B:
 //      a tenth of the IEEE-half operand error of the "fp16" mode, 1 % of bf16's).  The LayerNorm kernels are HBM-bound
-//      (6 TB/s) and their bytes drop 14 -> 12 (LN1) and 8 -> 7 (LN2): -1.5 % on the step.  OPT-IN (TAPCLIP_X24=1,
-//      tower.hip): a tower on this layout returns wrong rows when a second stream keeps the GPU busy beside it.
+//      (6 TB/s) and their bytes drop 14 -> 12 (LN1) and 8 -> 7 (LN2): -1.3 % on the step.  Default of the image
+//      tower's 16-bit modes (TAPCLIP_X24=0: fp32 stream).
 // PRE (XF = 2, ADD = 0): the row is first read as fp32 from x, normalised with (gamma_pre, beta_pre) -- ln_pre of the
 //   image tower -- and THAT is the residual row, written in the XF format; then the LayerNorm proper (block 0's ln_1)
 //   runs on it: one pass over the patch embeddings instead of an in-place fp32 ln_pre followed by a second kernel.
