@@ -513,7 +513,7 @@ def test_packed_fp32_probe_every_failing_encoding_is_one_the_library_check_rejec
     that is the set tests/test_abi.py keeps out of the library -- if ANY other encoding ever fails here, that check is
     no longer sufficient."""
     alone, beside = _pk_probe(tmp_path)
-    assert "0 of 96 encodings returned wrong results" in alone, alone
+    assert re.search(r"\b0 of \d+ encodings returned wrong results", alone), alone
     bad = [l for l in beside.splitlines() if "UNSAFE" in l]
     outside = [l for l in bad if "op_sel:[0,1" not in l]
     assert not outside, "encodings outside op_sel = [0,1,...] failed:\n" + "\n".join(outside)
