@@ -453,9 +453,10 @@ def test_image_tower_is_bit_stable_beside_a_busy_second_stream(eng, name, batch,
         for _ in range(20):
             big @ big
 
+    n_it = int(os.environ.get("TAPCLIP_STABILITY_ITERS", "10"))  # (soak runs: 200)
     for label, nb in (("text tower bf16x3", neighbour_text), ("torch matmul", neighbour_matmul)):
         differ = 0
-        for _ in range(10):
+        for _ in range(n_it):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 e = tower.encode_image(images, normalize=True)
@@ -463,7 +464,7 @@ def test_image_tower_is_bit_stable_beside_a_busy_second_stream(eng, name, batch,
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             differ += int(not torch.equal(e, base))
-        assert differ == 0, f"{name} batch {batch} {precision} beside {label}: {differ}/10 runs differ from the solo run"
+        assert differ == 0, f"{name} batch {batch} {precision} beside {label}: {differ}/{n_it} runs differ from the solo run"
 
 
 def test_text_tower_is_bit_stable_beside_the_image_tower(eng):
@@ -480,7 +481,7 @@ def test_text_tower_is_bit_stable_beside_the_image_tower(eng):
         text = eng.TextTower(cfg, sd, DEV, precision)
         base = [t.clone() for t in text.forward(prompts, want_mean=True).values() if torch.is_tensor(t)]
         torch.cuda.synchronize()
-        for it in range(10):
+        for it in range(int(os.environ.get("TAPCLIP_STABILITY_ITERS", "10"))):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 tower.encode_image(images, normalize=True)
