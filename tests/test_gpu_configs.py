@@ -521,3 +521,35 @@ def test_packed_fp32_probe_every_failing_encoding_is_one_the_library_check_rejec
     for l in bad:  # and only in the last 16-lane quad
         q = [int(v) for v in l.split("quad:")[1].split()]
         assert q[0] == q[1] == q[2] == 0, l
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_fullmodel_overlapped_towers_equal_the_serial_run_bit_for_bit(precision):
+    """FullModel(overlap_towers=True) -- image tower on a second stream beside the text tower, the default -- against
+    overlap_towers=False on the same weights: identical logits, every time (configs[2]'s shapes at batch 64; forward
+    and one training step's context gradients)."""
+    g = golden("fullmodel_intended_vitb16_c65")
+    model, _ = _build_full("ViT-B-16", g, "intended", precision)
+    cfg = configs.get_config("ViT-B-16")
+    images = synth.make_images(64, cfg, 5).to(DEV)
+    labels = (torch.arange(64) % 65).to(DEV)
+    model.eval()
+    model.overlap_towers = False
+    with torch.no_grad():
+        base = model(images)["logits"].clone()
+    model.train()
+    model(images, labels)["loss"].backward()
+    names = g["class_names"].tolist()
+    base_grad = torch.stack([model.prompt_learner.context_bank[c].grad.clone() for c in names], 0)
+    model.overlap_towers = True
+    for it in range(int(os.environ.get("TAPCLIP_STABILITY_ITERS", "10"))):
+        model.eval()
+        with torch.no_grad():
+            got = model(images)["logits"]
+        assert torch.equal(got, base), f"{precision}, forward {it}: overlapped towers differ from the serial run by {(got - base).abs().max().item():.3e}"
+        model.train()
+        for c in names:
+            model.prompt_learner.context_bank[c].grad = None
+        model(images, labels)["loss"].backward()
+        grad = torch.stack([model.prompt_learner.context_bank[c].grad for c in names], 0)
+        assert torch.equal(grad, base_grad), f"{precision}, training step {it}: context gradients differ by {(grad - base_grad).abs().max().item():.3e}"
