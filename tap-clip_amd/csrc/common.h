@@ -7,12 +7,13 @@
 // Measured on MI355X (tools/probes/pk_opsel_table.hip, profiles/r02_pk_opsel_table.txt): a packed-fp32 op whose LOW
 // result takes src0's low register and src1's HIGH register -- op_sel:[0,1] / [0,1,x], any op_sel_hi -- returns wrong
 // values in lanes 48..63 while a wave of ANOTHER kernel runs LDS-fed MFMAs on the same CU (1-12 % of those results
-// beside a GEMM-like kernel on a second stream; never alone; the other 72 of the 96 encodings never).  hipcc emits
-// that encoding on its own from plain C++ (80 of them in this library's LayerNorm kernels: the pair swap of a row
-// sum, gamma * (x, y) with the pair held as (y, x)), so a LayerNorm beside the other tower's GEMMs returned rows with
-// a component at beta, or a row sum short of 16 lanes.  Files whose kernels can run beside another stream's GEMM and
-// in which the compiler forms such ops are compiled this way; tests/test_abi.py disassembles the built libraries
-// and fails on any packed-fp32 op with op_sel = [0,1,...].
+// beside a GEMM-like kernel on a second stream; never alone; the other 72 of the 96 encodings never; nor the form with
+// src0 == src1, the pair swap of a row sum).  hipcc emits that encoding on its own from plain C++ -- in this library
+// gamma * (x, y) with the pair held as (y, x), in the LayerNorm of the 24-bit residual planes -- so that LayerNorm
+// returned, beside the other tower's GEMMs, rows with one component at beta.  Files whose kernels can run beside
+// another stream's GEMM and in which the compiler forms such ops are compiled this way; tests/test_abi.py
+// disassembles the built libraries and fails on any packed-fp32 op with op_sel = [0,1,...] (same-register form
+// included: the check is on the encoding).
 #if defined(TAPCLIP_TU_NO_PK_F32) && defined(__HIP_DEVICE_COMPILE__)
 #pragma clang attribute push(__attribute__((target("no-packed-fp32-ops"))), apply_to = function)
 #define TAPCLIP_TU_NO_PK_F32_END _Pragma("clang attribute pop")

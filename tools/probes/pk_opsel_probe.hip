@@ -26,14 +26,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); exit(1); }       \
   } while (0)
 
-constexpr int NPAT = 12;
+constexpr int NPAT = 14;
 static const char* PAT_NAME[NPAT] = {
     "pk_fma default                               ", "pk_fma op_sel:[0,1,0] op_sel_hi:[1,0,1] (swap) ",
     "pk_mul op_sel_hi:[0,1] (broadcast src0.lo)    ", "pk_add op_sel:[0,1] op_sel_hi:[1,0] (swap)    ",
     "pk_fma op_sel:[1,0,0] (src0.hi for both)      ", "pk_fma swap, operands fresh from global loads ",
     "pk_add op_sel_hi:[1,0] neg (broadcast src1.lo)", "pk_fma op_sel_hi:[1,1,0] (broadcast src2.lo)  ",
     "pk_mul op_sel:[0,1] op_sel_hi:[1,0] (swap)    ", "pk_mov_b32 op_sel:[1,0] (swap)                ",
-    "pk_mul op_sel:[1,1] op_sel_hi:[0,0] (full swap)", "pk_fma op_sel:[0,0,1] op_sel_hi:[1,1,0] (swap2)"};
+    "pk_mul op_sel:[1,1] op_sel_hi:[0,0] (full swap)", "pk_fma op_sel:[0,0,1] op_sel_hi:[1,1,0] (swap2)",
+    "pk_add v, X, X op_sel:[0,1] op_sel_hi:[1,0]   ", "pk_mul v, X, X op_sel:[0,1] op_sel_hi:[1,0]   "};
 
 __device__ __forceinline__ float sfma(float a, float b, float c) {
   float r;
@@ -55,7 +56,7 @@ __device__ __forceinline__ float sadd(float a, float b) {
 __global__ __launch_bounds__(256) void victim(int iters, const float* __restrict__ src, unsigned long long* counts) {
   const int lane = threadIdx.x & 63, quad = lane >> 4;
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned bad[NPAT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned bad[NPAT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   f32x2 a = {1.0f + 0.001f * (gid & 1023), -0.5f + 0.003f * (gid & 511)};
   f32x2 b = {0.75f + 0.002f * (gid & 255), 1.25f - 0.001f * (gid & 127)};
   f32x2 c = {0.01f * (gid & 63), -0.02f * (gid & 31)};
@@ -89,6 +90,11 @@ __global__ __launch_bounds__(256) void victim(int iters, const float* __restrict
     bad[10] += (r.x != smul(a.y, b.y)) | (r.y != smul(a.x, b.x));
     asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     bad[11] += (r.x != sfma(a.x, b.x, c.y)) | (r.y != sfma(a.y, b.y, c.x));
+    // the form hipcc uses for a row sum: BOTH sources are the same register pair
+    asm volatile("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a));
+    bad[12] += (r.x != sadd(a.x, a.y)) | (r.y != sadd(a.y, a.x));
+    asm volatile("v_pk_mul_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(b));
+    bad[13] += (r.x != smul(b.x, b.y)) | (r.y != smul(b.y, b.x));
     a.x += 0.0009765625f; b.y -= 0.00048828125f; c.x += 0.001953125f;  // keep the operands moving
   }
 #pragma unroll
