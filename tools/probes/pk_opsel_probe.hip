@@ -153,6 +153,37 @@ __global__ __launch_bounds__(256) void gemm_hog(int iters, float* sink) {
   if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.678f) sink[0] = 1.f;
 }
 
+// variants of the GEMM-like hog, to see which ingredient matters
+template <bool FEED, bool BARRIER>
+__global__ __launch_bounds__(256) void gemm_hog_v(int iters, float* sink) {
+  __shared__ bf16x8 buf[2048];
+  for (int i = threadIdx.x; i < 2048; i += 256)
+    for (int e = 0; e < 8; ++e) buf[i][e] = (__bf16)(0.001f * (i + e));
+  __syncthreads();
+  f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  bf16x8 ra, rb, junk = buf[threadIdx.x];
+  for (int i = 0; i < 8; ++i) { ra[i] = (__bf16)(0.001f * (threadIdx.x + i)); rb[i] = (__bf16)(0.002f * (threadIdx.x - i)); }
+  int idx = threadIdx.x;
+  for (int it = 0; it < iters; ++it) {
+    const bf16x8 a0 = buf[idx & 2047], a1 = buf[(idx + 256) & 2047], b0 = buf[(idx + 512) & 2047], b1 = buf[(idx + 768) & 2047];
+    if (FEED) {  // the LDS reads feed the MFMAs
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[3], 0, 0, 0);
+    } else {     // same LDS traffic and same MFMAs, but the MFMAs run on registers
+      for (int e = 0; e < 8; ++e) junk[e] = (__bf16)((float)junk[e] + (float)a0[e] + (float)a1[e] + (float)b0[e] + (float)b1[e]);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra, rb, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra, rb, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra, rb, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra, rb, acc[3], 0, 0, 0);
+    }
+    idx += 33;
+    if (BARRIER && (it & 15) == 15) __syncthreads();
+  }
+  if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + (float)junk[0] == 12345.678f) sink[0] = 1.f;
+}
+
 // memory hog: streams a large buffer
 __global__ __launch_bounds__(256) void mem_hog(const f32x4* __restrict__ p, size_t n, int passes, float* sink) {
   f32x4 s = {0, 0, 0, 0};
@@ -179,8 +210,8 @@ int main(int argc, char** argv) {
   hipStream_t s1, s2;
   CHECK(hipStreamCreate(&s1));
   CHECK(hipStreamCreate(&s2));
-  const char* modes[5] = {"alone", "beside an MFMA hog", "beside a memory hog", "beside an LDS hog", "beside a GEMM-like hog (LDS + MFMA + barriers)"};
-  for (int mode = 0; mode < 5; ++mode) {
+  const char* modes[8] = {"alone", "beside an MFMA hog", "beside a memory hog", "beside an LDS hog", "beside a GEMM-like hog (LDS + MFMA + barriers)", "beside LDS-fed MFMAs WITHOUT barriers", "beside LDS reads + MFMAs on REGISTERS, with barriers", "beside LDS reads + MFMAs on registers, no barriers"};
+  for (int mode = 0; mode < 8; ++mode) {
     CHECK(hipMemset(counts, 0, NPAT * 4 * sizeof(unsigned long long)));
     CHECK(hipDeviceSynchronize());
     const int rounds = argc > 1 ? atoi(argv[1]) : 40;
@@ -188,6 +219,9 @@ int main(int argc, char** argv) {
       if (mode == 1) hipLaunchKernelGGL(mfma_hog, dim3(1024), dim3(256), 0, s2, 40000, sink);
       if (mode == 3) hipLaunchKernelGGL(lds_hog, dim3(1024), dim3(256), 0, s2, 40000, sink);
       if (mode == 4) hipLaunchKernelGGL(gemm_hog, dim3(1024), dim3(256), 0, s2, 40000, sink);
+      if (mode == 5) hipLaunchKernelGGL((gemm_hog_v<true, false>), dim3(1024), dim3(256), 0, s2, 40000, sink);
+      if (mode == 6) hipLaunchKernelGGL((gemm_hog_v<false, true>), dim3(1024), dim3(256), 0, s2, 40000, sink);
+      if (mode == 7) hipLaunchKernelGGL((gemm_hog_v<false, false>), dim3(1024), dim3(256), 0, s2, 40000, sink);
       if (mode == 2) hipLaunchKernelGGL(mem_hog, dim3(2048), dim3(256), 0, s2, big, big_n, 2, sink);
       // many small victim launches, like the tower's 100-block LayerNorm
       for (int k = 0; k < 50; ++k) hipLaunchKernelGGL(victim, dim3(100), dim3(256), 0, s1, 64, src, counts);
