@@ -468,11 +468,6 @@ int run_blocks(tapclip_tower* t, float* x, int64_t n_seq, int tokens, int causal
       ProfScope ps(t, 1, s);
       // LN2 normalises x + branch without writing x back (8 instead of 12 B/element); the last block does write,
       // so that only c_proj's branch is pending on return
-      static const bool dbg_add1 = getenv("TAPCLIP_DEBUG_LN2_ADD1") != nullptr;
-      if (x24 && dbg_add1 && !last) {
-        // debug: x + a written back (then the next LN1 must add only d): NOT numerically identical, only for race hunting
-        HIP_TRY(launch_layernorm_x24(1, 0, nullptr, 0, w.x24_hi, w.x24_lo, w.a_hi, nullptr, nullptr, nullptr, L.ln2_g, L.ln2_b, M, D, w.xn_hi, s));
-      } else
       if (x24) HIP_TRY(launch_layernorm_x24(last ? 1 : 2, 0, nullptr, 0, w.x24_hi, w.x24_lo, w.a_hi, nullptr, nullptr, nullptr, L.ln2_g, L.ln2_b, M, D, w.xn_hi, s));
       else HIP_TRY(launch_add_layernorm_ex(last ? 1 : 2, x, w.a_hi, w.a_lo, nullptr, nullptr, L.ln2_g, L.ln2_b, M, D, w.xn_hi, w.xn_lo, s, stream_x));
       DBG_SYNC(1, s);
