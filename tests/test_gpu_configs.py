@@ -14,6 +14,7 @@ REFERENCE's own classes (oracle/make_golden.py):
 Tolerances as in test_gpu_parity.py: TOL = 1e-3 for the modes that claim BASELINE.json's bound (bf16x3, and fp16 =
 IEEE-half image tower + split-bf16 text tower), TOL_BF16 = 2e-2 for plain bf16 (reported, not the parity claim)."""
 import os
+import re
 import subprocess
 import sys
 
