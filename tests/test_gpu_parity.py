@@ -283,14 +283,16 @@ def test_encode_image_full_batch_properties(eng, vitb16):
     assert torch.allclose(a.norm(dim=-1), torch.ones(256, device=DEV), atol=1e-5)
     small = tower.encode_image(images[:8].clone(), normalize=True)
     assert torch.equal(small, a[:8]), "embedding of an image must not depend on the rest of the batch"
-    # the last row tiles of the N = 768, K = 3072 GEMM are K-split over the CUs a partial round would idle
-    # (gemm256.hip "tail split"): their fp32 sums associate differently, so those rows match a small batch
-    # to bf16 round-off instead of bitwise
-    last = tower.encode_image(images[-8:].clone(), normalize=True)
-    assert rel_l2(last.cpu(), a[-8:].cpu()) < TOL_EMU
     with torch.no_grad():
         ref = clip_ref.encode_image(images[:2].cpu(), sd, clip_ref.CONFIGS["ViT-B-16"], normalize=True)
-    assert rel_l2(a[:2].cpu(), ref) < TOL_BF16
+    own = rel_l2(a[:2].cpu(), ref)  # this mode's rounding error against the fp32 oracle (2.4e-3)
+    assert own < TOL_BF16
+    # the last row tiles of the N = 768, K = 3072 GEMM are K-split over the CUs a partial round would idle
+    # (gemm256.hip "tail split"): their fp32 sums associate differently, so those rows match a small batch
+    # to the mode's round-off instead of bitwise -- two roundings of one computation (bf16 operands, half residual
+    # stream) differ by less than 1.5x what either is off the exact result (measured 2.1e-3 against 2.4e-3)
+    last = tower.encode_image(images[-8:].clone(), normalize=True)
+    assert rel_l2(last.cpu(), a[-8:].cpu()) < 1.5 * own
 
 
 # ---- text side ----------------------------------------------------------------------------------
