@@ -10,6 +10,8 @@
 //   pool_project_bwd     d(token pick -> @ text_projection -> L2 norm)   (model_wrapper.py:73-75)
 //   logits_bwd           d(scale * img . txt^T) w.r.t. txt and log-scale  (model_wrapper.py:79)
 //   pack_transpose       W[N,K] fp32 -> W^T[K,N] bf16 hi (+ lo)
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -32,88 +34,108 @@ __device__ __forceinline__ void st_bf(bf16_t* hi, bf16_t* lo, int64_t i, float v
   }
 }
 
-// ---- attention backward.  One 256-thread workgroup per (sequence, head); T <= 96 (the text tower's
-// prompt_len + 77).  Everything is fp32: operands sit in LDS as fp32 and the five products run on the exact
-// f32-input MFMA (v_mfma_f32_16x16x4_f32: A[row = l & 15][k = l >> 4], B[k = l >> 4][col = l & 15], one float
-// per lane per operand), so bf16 and bf16x3 towers share one kernel and the result is fp32-accurate.
-// LDS: q, k, v, dO as [Tp][65] (Tp = T rounded up to 16, pad rows zero; 65: conflict-free row and column
-// walks) + P/dS [Tp][Tp+1] + delta[Tp].
+// ---- attention backward.  One 512-thread workgroup per (sequence, head); T <= 96 (the text tower's
+// prompt_len + 77).  The arithmetic is fp32: the five products run on the exact f32-input MFMA
+// (v_mfma_f32_16x16x4_f32: A[row = l & 15][k = l >> 4], B[k = l >> 4][col = l & 15], one float per lane per
+// operand), so bf16 and bf16x3 towers share one kernel and the result is fp32-accurate.
 //   S = q k^T (q carries the folded 1/sqrt(64)),  P = softmax(S),  dV = P^T dO,
 //   dP = dO v^T,  delta_i = sum_d dO_id O_id,  dS = P (dP - delta),  dq = dS k,  dk = dS^T q.
-constexpr int BWD_LD = 65;
+// LDS: TWO operand buffers [Tp][LDO] (Tp = T rounded up to 16, pad rows zero), staged three times -- (q, k) for S,
+// (dO, v) for dV and dS, (q, k) again for dq and dk: the re-reads come from L2 -- plus P / dS [Tp][Tp+1] and delta[Tp].
+// H16 (no low planes, i.e. the bf16 tower): the operands stay 16-bit in LDS and are widened when read, 63 KB for
+// T = 93, so TWO workgroups share a CU; with fp32 operands (bf16x3: hi + lo summed) it is 88 KB and one.  (Round 2:
+// all four operands resident as fp32 were 137 KB -- 520 workgroups of the 65 x 8 text tower at one per CU are
+// 2.03 rounds that cost three: 123 us per launch.)
+constexpr int BWD_LD = 65;    // fp32 operand row (conflict-free row and column walks)
+constexpr int BWD_LD16 = 66;  // 16-bit operand row: 33 dwords
 
 __device__ __forceinline__ f32x4_t mfma4(float a, float b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-template <int NT>  // NT = Tp / 16 key / query tiles: compile-time trip counts, so the LDS reads of a product pipeline
+template <int NT, bool H16>  // NT = Tp / 16 key / query tiles: compile-time trip counts, so the LDS reads of a product pipeline
 __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs a) {
   extern __shared__ float sh[];
   const int T = a.T, D = a.D;
   constexpr int Tp = NT * 16, nt = NT, LP = Tp + 1;
   constexpr int NW = 8;  // waves
-  float* q = sh;
-  float* k = q + Tp * BWD_LD;
-  float* v = k + Tp * BWD_LD;
-  float* dO = v + Tp * BWD_LD;
-  float* P = dO + Tp * BWD_LD;  // [Tp][Tp+1]
+  constexpr int LDO = H16 ? BWD_LD16 : BWD_LD;
+  typedef typename std::conditional<H16, bf16_t, float>::type op_t;
+  float* P = sh;  // [Tp][Tp+1]
   float* delta = P + Tp * LP;
+  op_t* bufA = reinterpret_cast<op_t*>(delta + Tp);
+  op_t* bufB = bufA + Tp * LDO;
+  auto ld = [](const op_t* b, int idx) -> float {
+    if constexpr (H16) return bf2f(b[idx]);
+    else return b[idx];
+  };
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
   const int seq = blockIdx.x / a.H, head = blockIdx.x - seq * a.H;
   const int64_t row0 = (int64_t)seq * T;
-  const int64_t ld = 3 * (int64_t)D;
+  const int64_t ldq = 3 * (int64_t)D;
   const int qcol = head * 64, kcol = D + head * 64, vcol = 2 * D + head * 64;
 
-  // stage q, k, v, dO as fp32: 8 bf16 (16 B) per thread and array, hi (+ lo) planes
-  for (int e = tid; e < Tp * 8; e += 512) {
-    const int i = e >> 3, d0 = (e & 7) * 8;
-    float fq[8], fk[8], fv[8], fo[8];
+  // Staging of one [T, 64] slice (hi [+ lo] planes, row stride `stride`, first column `col`) into an operand buffer, 8
+  // elements (16 B per plane) per thread and step, in two halves: the global loads into registers (issued early, so
+  // that they fly under the previous phase's arithmetic) and the LDS writes.
+  constexpr int NSTEP = (Tp * 8 + 511) / 512;
+  struct Staged { uint4 h[NSTEP], l[NSTEP]; };
+  auto stage_load = [&](Staged& r, const bf16_t* hi, const bf16_t* lo, int64_t stride, int col) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) fq[u] = fk[u] = fv[u] = fo[u] = 0.f;
-    if (i < T) {
-      auto ld8 = [&](const bf16_t* hi, const bf16_t* lo, int64_t g, float (&f)[8]) {
-        const uint4 h = *reinterpret_cast<const uint4*>(hi + g);
-        const uint32_t hw[4] = {h.x, h.y, h.z, h.w};
+    for (int it = 0; it < NSTEP; ++it) {
+      const int e = tid + 512 * it, i = e >> 3, d0 = (e & 7) * 8;
+      r.h[it] = make_uint4(0, 0, 0, 0);
+      r.l[it] = make_uint4(0, 0, 0, 0);
+      if (e < Tp * 8 && i < T) {
+        const int64_t g = (row0 + i) * stride + col + d0;
+        r.h[it] = *reinterpret_cast<const uint4*>(hi + g);
+        if (!H16 && lo != nullptr) r.l[it] = *reinterpret_cast<const uint4*>(lo + g);
+      }
+    }
+  };
+  auto stage_store = [&](op_t* dst, const Staged& r) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          f[2 * u] = bf2f((bf16_t)(hw[u] & 0xFFFF));
-          f[2 * u + 1] = bf2f((bf16_t)(hw[u] >> 16));
+    for (int it = 0; it < NSTEP; ++it) {
+      const int e = tid + 512 * it, i = e >> 3, d0 = (e & 7) * 8;
+      if (e >= Tp * 8) continue;
+      const uint32_t hw[4] = {r.h[it].x, r.h[it].y, r.h[it].z, r.h[it].w}, lw[4] = {r.l[it].x, r.l[it].y, r.l[it].z, r.l[it].w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if constexpr (H16) {
+          *reinterpret_cast<uint32_t*>(dst + i * LDO + d0 + 2 * u) = hw[u];  // (LDO and d0 are even: 4-byte aligned)
+        } else {
+          // (bf2f(0) + bf2f(0) = 0: absent low planes and pad rows need no special case)
+          dst[i * LDO + d0 + 2 * u] = bf2f((bf16_t)(hw[u] & 0xFFFF)) + bf2f((bf16_t)(lw[u] & 0xFFFF));
+          dst[i * LDO + d0 + 2 * u + 1] = bf2f((bf16_t)(hw[u] >> 16)) + bf2f((bf16_t)(lw[u] >> 16));
         }
-        if (lo != nullptr) {
-          const uint4 l = *reinterpret_cast<const uint4*>(lo + g);
-          const uint32_t lw[4] = {l.x, l.y, l.z, l.w};
+      }
+    }
+  };
+
+  Staged ra, rb;
+  stage_load(ra, a.qkv_hi, a.qkv_lo, ldq, qcol);  // q
+  stage_load(rb, a.qkv_hi, a.qkv_lo, ldq, kcol);  // k
+  {  // delta_i = <dO_i, O_i>: one wave per row, both read straight from global; all of a wave's rows in flight at once
+    constexpr int RPW = Tp / NW;
+    float sd[RPW];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            f[2 * u] += bf2f((bf16_t)(lw[u] & 0xFFFF));
-            f[2 * u + 1] += bf2f((bf16_t)(lw[u] >> 16));
-          }
-        }
-      };
-      const int64_t g = (row0 + i) * ld + d0;
-      ld8(a.qkv_hi, a.qkv_lo, g + qcol, fq);
-      ld8(a.qkv_hi, a.qkv_lo, g + kcol, fk);
-      ld8(a.qkv_hi, a.qkv_lo, g + vcol, fv);
-      ld8(a.dout_hi, a.dout_lo, (row0 + i) * D + head * 64 + d0, fo);
+    for (int u = 0; u < RPW; ++u) {
+      const int i = wave + NW * u;
+      sd[u] = 0.f;
+      if (i < T) {
+        const int64_t g = (row0 + i) * D + head * 64 + lane;
+        sd[u] = ld_bf(a.dout_hi, a.dout_lo, g) * ld_bf(a.out_hi, a.out_lo, g);
+      }
     }
+    stage_store(bufA, ra);
+    stage_store(bufB, rb);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      q[i * BWD_LD + d0 + u] = fq[u];
-      k[i * BWD_LD + d0 + u] = fk[u];
-      v[i * BWD_LD + d0 + u] = fv[u];
-      dO[i * BWD_LD + d0 + u] = fo[u];
+    for (int u = 0; u < RPW; ++u) {
+      const float t = wave_sum(sd[u]);
+      if (lane == 0) delta[wave + NW * u] = t;
     }
-  }
-  // delta_i = <dO_i, O_i>: one wave per row, O read straight from global
-  for (int i = wave; i < Tp; i += NW) {
-    float s = 0.f;
-    if (i < T) {
-      const int64_t g = (row0 + i) * D + head * 64 + lane;
-      s = ld_bf(a.dout_hi, a.dout_lo, g) * ld_bf(a.out_hi, a.out_lo, g);
-    }
-    s = wave_sum(s);
-    if (lane == 0) delta[i] = s;
   }
   __syncthreads();
 
@@ -121,10 +143,13 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs a) {
   for (int tile = wave; tile < nt * nt; tile += NW) {
     const int ti = tile / nt, tj = tile - ti * nt;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    const float* qa = q + (ti * 16 + lr) * BWD_LD + lq;
-    const float* kb = k + (tj * 16 + lr) * BWD_LD + lq;
+    const op_t* qa = bufA + (ti * 16 + lr) * LDO + lq;
+    const op_t* kb = bufB + (tj * 16 + lr) * LDO + lq;
+    float av[16], bv[16];  // all operands of the tile first, then the MFMA chain: one LDS wait instead of sixteen
 #pragma unroll
-    for (int d = 0; d < 64; d += 4) acc = mfma4(qa[d], kb[d], acc);
+    for (int u = 0; u < 16; ++u) { av[u] = ld(qa, 4 * u); bv[u] = ld(kb, 4 * u); }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc = mfma4(av[u], bv[u], acc);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int i = ti * 16 + 4 * lq + e, j = tj * 16 + lr;
@@ -133,51 +158,84 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs a) {
       P[i * LP + j] = sv;
     }
   }
-  __syncthreads();
-  // row softmax (pad query rows see all-finite scores of zero vectors; their dO is zero, so they never count)
-  for (int i = wave; i < Tp; i += NW) {
-    float mx = -INFINITY;
-    for (int j = lane; j < Tp; j += 64) mx = fmaxf(mx, P[i * LP + j]);
-    mx = wave_max(mx);
-    float sum = 0.f;
-    for (int j = lane; j < Tp; j += 64) {
-      const float p = expf(P[i * LP + j] - mx);
-      P[i * LP + j] = p;
-      sum += p;
+  stage_load(ra, a.dout_hi, a.dout_lo, D, head * 64);  // dO  (in flight under the barrier and the softmax)
+  stage_load(rb, a.qkv_hi, a.qkv_lo, ldq, vcol);       // v
+  __syncthreads();  // (q, k are free from here on)
+  // row softmax (pad query rows see all-finite scores of zero vectors; their dO is zero, so they never count): four
+  // rows per wave at a time, 16 lanes and NT elements per lane each, reductions by four xor-shuffles inside the 16-lane
+  // groups (one row per wave with 64-lane reductions was 19 us of the kernel)
+  {
+    const int g = lane >> 4, l16 = lane & 15;
+    constexpr int RPW = Tp / NW;
+#pragma unroll
+    for (int b = 0; b < (RPW + 3) / 4; ++b) {
+      const int u = 4 * b + g;
+      const bool on = u < RPW;
+      const int i = on ? wave + NW * u : 0;
+      float pv[NT], mx = -INFINITY;
+#pragma unroll
+      for (int m = 0; m < NT; ++m) {
+        pv[m] = on ? P[i * LP + l16 + 16 * m] : 0.f;
+        mx = fmaxf(mx, pv[m]);
+      }
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+      float sum = 0.f;
+#pragma unroll
+      for (int m = 0; m < NT; ++m) {
+        pv[m] = __expf(pv[m] - mx);
+        sum += pv[m];
+      }
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 16);
+      const float inv = 1.0f / sum;
+      if (on) {
+#pragma unroll
+        for (int m = 0; m < NT; ++m) P[i * LP + l16 + 16 * m] = pv[m] * inv;
+      }
     }
-    sum = wave_sum(sum);
-    const float inv = 1.0f / sum;
-    for (int j = lane; j < Tp; j += 64) P[i * LP + j] *= inv;
   }
+  stage_store(bufA, ra);
+  stage_store(bufB, rb);
   __syncthreads();
   // dV[j][d] = sum_i P[i][j] dO[i][d]   (tile (tj, td): A[row j][k i] = P[i][j], B[k i][col d] = dO[i][d], K = Tp)
   for (int tile = wave; tile < nt * 4; tile += NW) {
     const int tj = tile >> 2, td = tile & 3;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    float av[Tp / 4], bv[Tp / 4];
 #pragma unroll
-    for (int i0 = 0; i0 < Tp; i0 += 4)
-      acc = mfma4(P[(i0 + lq) * LP + tj * 16 + lr], dO[(i0 + lq) * BWD_LD + td * 16 + lr], acc);
+    for (int u = 0; u < Tp / 4; ++u) { av[u] = P[(4 * u + lq) * LP + tj * 16 + lr]; bv[u] = ld(bufA, (4 * u + lq) * LDO + td * 16 + lr); }
+#pragma unroll
+    for (int u = 0; u < Tp / 4; ++u) acc = mfma4(av[u], bv[u], acc);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int j = tj * 16 + 4 * lq + e;
-      if (j < T) st_bf(a.dqkv_hi, a.dqkv_lo, (row0 + j) * ld + vcol + td * 16 + lr, acc[e]);
+      if (j < T) st_bf(a.dqkv_hi, a.dqkv_lo, (row0 + j) * ldq + vcol + td * 16 + lr, acc[e]);
     }
   }
+  stage_load(ra, a.qkv_hi, a.qkv_lo, ldq, qcol);  // q  (in flight under dS)
+  stage_load(rb, a.qkv_hi, a.qkv_lo, ldq, kcol);  // k
   __syncthreads();
   // dS[i][j] = P[i][j] (dO_i . v_j - delta_i), in place
   for (int tile = wave; tile < nt * nt; tile += NW) {
     const int ti = tile / nt, tj = tile - ti * nt;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    const float* oa = dO + (ti * 16 + lr) * BWD_LD + lq;
-    const float* vb = v + (tj * 16 + lr) * BWD_LD + lq;
+    const op_t* oa = bufA + (ti * 16 + lr) * LDO + lq;
+    const op_t* vb = bufB + (tj * 16 + lr) * LDO + lq;
+    float av[16], bv[16];
 #pragma unroll
-    for (int d = 0; d < 64; d += 4) acc = mfma4(oa[d], vb[d], acc);
+    for (int u = 0; u < 16; ++u) { av[u] = ld(oa, 4 * u); bv[u] = ld(vb, 4 * u); }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc = mfma4(av[u], bv[u], acc);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int i = ti * 16 + 4 * lq + e, j = tj * 16 + lr;
       P[i * LP + j] *= (acc[e] - delta[i]);
     }
   }
+  __syncthreads();  // (dO, v are free)
+  stage_store(bufA, ra);
+  stage_store(bufB, rb);
   __syncthreads();
   // dq[i][d] = sum_j dS[i][j] k[j][d];   dk[j][d] = sum_i dS[i][j] q[i][d]
   for (int tile = wave; tile < nt * 4 * 2; tile += NW) {
@@ -185,19 +243,20 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs a) {
     const int tl = is_dk ? tile - nt * 4 : tile;
     const int tr = tl >> 2, td = tl & 3;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    float av[Tp / 4], bv[Tp / 4];
     if (!is_dk) {
 #pragma unroll
-      for (int j0 = 0; j0 < Tp; j0 += 4)
-        acc = mfma4(P[(tr * 16 + lr) * LP + j0 + lq], k[(j0 + lq) * BWD_LD + td * 16 + lr], acc);
+      for (int u = 0; u < Tp / 4; ++u) { av[u] = P[(tr * 16 + lr) * LP + 4 * u + lq]; bv[u] = ld(bufB, (4 * u + lq) * LDO + td * 16 + lr); }
     } else {
 #pragma unroll
-      for (int i0 = 0; i0 < Tp; i0 += 4)
-        acc = mfma4(P[(i0 + lq) * LP + tr * 16 + lr], q[(i0 + lq) * BWD_LD + td * 16 + lr], acc);
+      for (int u = 0; u < Tp / 4; ++u) { av[u] = P[(4 * u + lq) * LP + tr * 16 + lr]; bv[u] = ld(bufA, (4 * u + lq) * LDO + td * 16 + lr); }
     }
+#pragma unroll
+    for (int u = 0; u < Tp / 4; ++u) acc = mfma4(av[u], bv[u], acc);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int rr = tr * 16 + 4 * lq + e;
-      if (rr < T) st_bf(a.dqkv_hi, a.dqkv_lo, (row0 + rr) * ld + (is_dk ? kcol : qcol) + td * 16 + lr, acc[e]);
+      if (rr < T) st_bf(a.dqkv_hi, a.dqkv_lo, (row0 + rr) * ldq + (is_dk ? kcol : qcol) + td * 16 + lr, acc[e]);
     }
   }
 }
@@ -336,36 +395,44 @@ inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
 
-size_t attn_bwd_lds_bytes(int T) {
+namespace {
+size_t attn_bwd_lds(int T, bool h16) {
   const int Tp = (T + 15) & ~15;
-  return (size_t)(4 * Tp * BWD_LD + Tp * (Tp + 1) + Tp) * sizeof(float);
+  return (size_t)(Tp * (Tp + 1) + Tp) * sizeof(float) + (h16 ? (size_t)2 * Tp * BWD_LD16 * 2 : (size_t)2 * Tp * BWD_LD * sizeof(float));
 }
+}  // namespace
+size_t attn_bwd_lds_bytes(int T) { return attn_bwd_lds(T, false); }  // the larger (fp32-operand) variant
 
-template <int NT>
-hipError_t launch_attn_bwd_t(const AttnBwdArgs& a, size_t lds, hipStream_t s) {
+template <int NT, bool H16>
+hipError_t launch_attn_bwd_t(const AttnBwdArgs& a, hipStream_t s) {
   static bool attr = false;
+  const size_t lds = attn_bwd_lds(NT * 16, H16);
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)attn_bwd_lds_bytes(NT * 16));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<NT, H16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
     if (e != hipSuccess) return e;
     attr = true;
   }
-  hipLaunchKernelGGL(attn_bwd_kernel<NT>, dim3((unsigned)(a.n_seq * a.H)), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((attn_bwd_kernel<NT, H16>), dim3((unsigned)(a.n_seq * a.H)), dim3(512), lds, s, a);
   return hipGetLastError();
 }
 
 hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s) {
   if (a.T <= 0 || a.T > 96 || a.D != a.H * 64 || a.n_seq <= 0 || a.D % 8 != 0) return hipErrorInvalidValue;
-  const size_t lds = attn_bwd_lds_bytes(a.T);
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (attn_bwd_lds_bytes(a.T) > 160 * 1024) return hipErrorInvalidValue;
+  // 16-bit operands in LDS when no tensor has a low plane (the bf16 tower)
+  const bool h16 = a.qkv_lo == nullptr && a.dout_lo == nullptr;
+#define TAPCLIP_ABWD_CASE(N) \
+  case N: return h16 ? launch_attn_bwd_t<N, true>(a, s) : launch_attn_bwd_t<N, false>(a, s);
   switch ((a.T + 15) / 16) {
-    case 1: return launch_attn_bwd_t<1>(a, lds, s);
-    case 2: return launch_attn_bwd_t<2>(a, lds, s);
-    case 3: return launch_attn_bwd_t<3>(a, lds, s);
-    case 4: return launch_attn_bwd_t<4>(a, lds, s);
-    case 5: return launch_attn_bwd_t<5>(a, lds, s);
-    default: return launch_attn_bwd_t<6>(a, lds, s);
+    TAPCLIP_ABWD_CASE(1)
+    TAPCLIP_ABWD_CASE(2)
+    TAPCLIP_ABWD_CASE(3)
+    TAPCLIP_ABWD_CASE(4)
+    TAPCLIP_ABWD_CASE(5)
+    default: return h16 ? launch_attn_bwd_t<6, true>(a, s) : launch_attn_bwd_t<6, false>(a, s);
   }
+#undef TAPCLIP_ABWD_CASE
 }
 
 hipError_t launch_ln_bwd(const float* x, const float* gamma, const float* dy, int64_t rows, int32_t d, float* dres,
