@@ -270,26 +270,40 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
   if (row >= rows) return;
   const float* xr = x + row * d;
   const float* gr = dy + row * d;
+  // the row lives in registers (d <= 1024: at most 16 elements per lane; the launcher checks): one read of x, dy and
+  // gamma instead of four passes over them (13.4 -> 12.4 us at 6 045 x 512: 48 MB of traffic either way)
+  constexpr int MAXE = 16;
+  float xv[MAXE], gv[MAXE];
   float s = 0.f;
-  for (int c = lane; c < d; c += 64) s += xr[c];
+#pragma unroll
+  for (int u = 0; u < MAXE; ++u) {
+    const int c = lane + 64 * u;
+    xv[u] = c < d ? xr[c] : 0.f;
+    gv[u] = c < d ? gr[c] * gamma[c] : 0.f;
+    s += xv[u];
+  }
   const float mean = wave_sum(s) / (float)d;
   float ss = 0.f;
-  for (int c = lane; c < d; c += 64) {
-    const float t = xr[c] - mean;
+#pragma unroll
+  for (int u = 0; u < MAXE; ++u) {
+    const float t = (lane + 64 * u < d) ? xv[u] - mean : 0.f;
+    xv[u] = t;
     ss += t * t;
   }
   const float rstd = rsqrtf(wave_sum(ss) / (float)d + 1e-5f);
   float sg = 0.f, sgx = 0.f;
-  for (int c = lane; c < d; c += 64) {
-    const float g = gr[c] * gamma[c];
-    sg += g;
-    sgx += g * (xr[c] - mean) * rstd;
+#pragma unroll
+  for (int u = 0; u < MAXE; ++u) {
+    xv[u] *= rstd;  // xhat
+    sg += gv[u];
+    sgx += gv[u] * xv[u];
   }
   sg = wave_sum(sg) / (float)d;
   sgx = wave_sum(sgx) / (float)d;
-  for (int c = lane; c < d; c += 64) {
-    const float xhat = (xr[c] - mean) * rstd;
-    dres[row * d + c] += rstd * (gr[c] * gamma[c] - sg - xhat * sgx);
+#pragma unroll
+  for (int u = 0; u < MAXE; ++u) {
+    const int c = lane + 64 * u;
+    if (c < d) dres[row * d + c] += rstd * (gv[u] - sg - xv[u] * sgx);
   }
 }
 
@@ -437,6 +451,7 @@ hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s) {
 
 hipError_t launch_ln_bwd(const float* x, const float* gamma, const float* dy, int64_t rows, int32_t d, float* dres,
                          hipStream_t s) {
+  if (rows <= 0 || d <= 0 || d > 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, gamma, dy, rows, d, dres);
   return hipGetLastError();
 }
