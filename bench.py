@@ -61,6 +61,16 @@ def encoder_flops_per_image(cfg):
     return v.layers * block + patch + 2 * d * cfg.embed_dim
 
 
+def source_sha16():
+    """sha256[:16] over the GEMM kernel sources the roofline object is about (what a PMC profile was taken on)"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("gemm256.hip", "gemm_mx8.hip", "common.h", "kernels.h"):
+        h.update(open(os.path.join(ROOT, "tap-clip_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cgroup_cpu_quota():
     """CPUs the container may use per its cgroup quota (v2 cpu.max, v1 cpu.cfs_quota_us), or None without a quota."""
     try:
@@ -79,6 +89,24 @@ def cgroup_cpu_quota():
     return None
 
 
+def spawn_ranks(n: int) -> int:
+    """Run this script as n ranks of one node under torch.distributed.run (rendezvous on 127.0.0.1, a free port) and
+    return the launcher's exit code.  Nothing here touches the GPU."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print(f"[bench] starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,20 +123,28 @@ def main():
     ap.add_argument("--no-input-side", action="store_true", help="skip the GPU preprocess measurement")
     ap.add_argument("--no-precisions", action="store_true", help="skip the bf16 / fp16 / fp8 comparison table")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--dump-logits", default=None, help="rank 0 saves the last step's [global_batch, classes] logits here (.npy): tests")
     args = ap.parse_args()
 
     t_start = time.perf_counter()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` as the driver calls it for N = 1: start the N ranks here, one process per GPU,
+        # BEFORE this process makes any GPU call (a process that has initialised the GPU must not be replaced, and
+        # need not hold a context beside its ranks); relay rank 0's JSON line (the children share stdout) and the
+        # launcher's exit code.
+        raise SystemExit(spawn_ranks(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     # (TAPCLIP_DIST_BACKEND=gloo rehearses N > 1 on a box with fewer GPUs than ranks: ranks share devices)
     backend = os.environ.get("TAPCLIP_DIST_BACKEND", "nccl")
+    if world > 1 and backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} with RCCL needs {world} GPUs, this box shows {torch.cuda.device_count()} "
+                         "(TAPCLIP_DIST_BACKEND=gloo rehearses the launch with ranks sharing devices; its number is not a scaling result)")
     dev = torch.device("cuda", local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
@@ -183,6 +219,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert out.shape == (args.batch * world, args.classes) and bool(torch.isfinite(out).all())
+    if args.dump_logits and rank == 0:
+        import numpy as np
+
+        np.save(args.dump_logits, out.cpu().numpy())
 
     total_images = args.batch * world * args.steps
     value = total_images / elapsed
@@ -196,37 +236,58 @@ def main():
                                f"{args.model} image encoder, synthetic {cfg.image_size}x{cfg.image_size}x3, "
                                f"batch {args.batch}/GPU, + all-gather of embeddings and {args.classes}-class logits",
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world, "tokens_per_image": cfg.n_tokens,
-                   "classes": args.classes, "parallelism": f"dp{world}", "weights": "seeded random (no checkpoint offline)"},
+                   "classes": args.classes, "parallelism": f"dp{world}", "weights": "seeded random (no checkpoint offline)",
+                   "collective": ("none (one rank)" if world == 1 else
+                                  f"RCCL all_gather_into_tensor of the [{args.batch}, {cfg.embed_dim}] fp32 embeddings over xGMI" if backend == "nccl" else
+                                  f"{backend} all_gather through host memory -- REHEARSAL, {world} ranks on "
+                                  f"{torch.cuda.device_count()} GPU(s): not a scaling measurement")},
         "logits_per_sec": round(value * args.classes, 1),
         "encoder_mfma_frac": round(enc_flops * args.batch * world * args.steps / elapsed / (PEAK_BF16_TFLOPS * 1e12 * world), 4),
         "encoder_gflop_per_image": round(enc_flops / 1e9, 3),
     }
 
-    if prof is not None:
+    def kernel_table(prof_, steps_):
+        """per-family table from the library's HIP-event sums + the GEMM family's FLOPs, time and launch count"""
         gf = gemm_flops_per_image(cfg)
-        kern = {}
-        g_ms = g_fl = 0.0
-        g_n = 0
-        for k, (ms, n) in prof.items():
+        kern_ = {}
+        g_ms_ = g_fl_ = 0.0
+        g_n_ = 0
+        for k, (ms, n) in prof_.items():
             if n == 0:
                 continue
-            e = {"ms_per_step": round(ms / args.steps, 4), "launches_per_step": n / args.steps, "avg_us": round(1e3 * ms / n, 2)}
+            e = {"ms_per_step": round(ms / steps_, 4), "launches_per_step": n / steps_, "avg_us": round(1e3 * ms / n, 2)}
             if k in gf:
-                fl = gf[k] * args.batch * args.steps
+                fl = gf[k] * args.batch * steps_
                 e["tflops"] = round(fl / (ms * 1e-3) / 1e12, 1)
-                g_ms += ms
-                g_fl += fl
-                g_n += n
-            kern[k] = e
+                g_ms_ += ms
+                g_fl_ += fl
+                g_n_ += n
+            kern_[k] = e
+        return kern_, g_ms_, g_fl_, g_n_
+
+    if prof is not None:
+        kern, g_ms, g_fl, g_n = kernel_table(prof, args.steps)
         achieved = g_fl / (g_ms * 1e-3) / 1e12
         # L2-fabric-side bytes per launch of the same kernel family from the committed PMC passes (separate
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this script, tools/pmc_traffic.py); None if absent
         traffic = None
-        tname = next((n for n in ("r02_pmc_traffic_bench.json", "r01_pmc_traffic_bench.json")
+        tname = next((n for n in ("r03_pmc_traffic_bench.json", "r02_pmc_traffic_bench.json", "r01_pmc_traffic_bench.json")
                       if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+        traffic_note = "no committed PMC pass for this configuration"
         if tname and args.batch == 256 and args.model == "ViT-B-16":
             try:
-                traffic = json.load(open(os.path.join(ROOT, "profiles", tname))).get("gemm_family_hbm_bytes_per_launch")
+                tj = json.load(open(os.path.join(ROOT, "profiles", tname)))
+                traffic = tj.get("gemm_family_hbm_bytes_per_launch")
+                traffic_note = (f"bytes/launch at the L2 fabric side (FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits included) from profiles/{tname}, "
+                                "a separate rocprofv3 --pmc run; algorithmic operand+output bytes per launch average 313 MB")
+                # the PMC pass is of the kernels as they were when it was taken: it names the source it measured, and a
+                # library built from other GEMM sources reports null rather than a stale figure
+                want = tj.get("gemm_source_sha16")
+                have = source_sha16()
+                if want != have:
+                    traffic = None
+                    traffic_note = (f"profiles/{tname} was measured on GEMM sources {want}, this library is built from {have}: "
+                                    "traffic withheld until the PMC passes are re-run (tools/collect_profiles.sh)")
             except Exception:
                 traffic = None
         fp8 = args.precision == "fp8"
@@ -238,8 +299,7 @@ def main():
                        if fp8 else
                        "gemm256_kernel<EPI,false,256,4> (persistent bf16 MFMA 16x16x32 GEMM, 256x256 tiles, 4-stage LDS-DMA ring): the QKV + out_proj + c_fc/GELU + c_proj launches"),
             "bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic,
-            "traffic_note": f"bytes/launch at the L2 fabric side (FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits included) from profiles/{tname}; algorithmic operand+output bytes per launch average 313 MB",
+            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
             "flops_per_launch": round(g_fl / g_n), "avg_launch_us": round(1e3 * g_ms / g_n, 2), "launches_per_step": g_n / args.steps,
             "measured_in": f"a second pass of the same {args.steps} steps with per-kernel HIP events ({1e3 * elapsed_events / args.steps:.3f} ms/step with the events in the stream)",
         }
@@ -461,7 +521,25 @@ def main():
                 dt_p = (time.perf_counter() - t1) / its
                 row = {"img_per_s": round(args.batch / dt_p, 1), "ms_per_step": round(1e3 * dt_p, 3),
                        "text_tower": cw._text.precision,
+                       # against the dense bf16 peak for every mode but fp8 (IEEE-half MFMAs run at the bf16 rate)
+                       "encoder_mfma_frac": round(enc_flops * args.batch / dt_p / ((PEAK_FP8_TFLOPS if prec == "fp8" else PEAK_BF16_TFLOPS) * 1e12), 4),
                        "embedding_rel_l2_vs_bf16x3": float("%.3e" % float((e - ref_emb).norm() / ref_emb.norm()))}
+                if events and prec == "fp16":
+                    # the mode that satisfies BOTH halves of north_star (speed and 1e-3) gets its own per-kernel table:
+                    # a pass of the same steps with the library's HIP events in the stream, as for the headline
+                    tw.profile(True)
+                    tw.profile_read()
+                    torch.cuda.synchronize(dev)
+                    for _ in range(its):
+                        engine.logits(tw.encode_image(images, normalize=True), text_feat, scale)
+                    torch.cuda.synchronize(dev)
+                    kern_p, g_ms_p, g_fl_p, g_n_p = kernel_table(tw.profile_read(), its)
+                    tw.profile(False)
+                    row["kernels"] = kern_p
+                    if g_ms_p > 0:
+                        row["gemm_family"] = {"achieved": round(g_fl_p / (g_ms_p * 1e-3) / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                              "frac": round(g_fl_p / (g_ms_p * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                              "avg_launch_us": round(1e3 * g_ms_p / g_n_p, 2)}
                 if oracle_logits is not None:
                     with contextlib.redirect_stdout(sys.stderr):
                         fm = FullModel(names, cw, prompt_len=args.prompt_len, class_specific=True).eval()
@@ -483,7 +561,10 @@ def main():
         if ok:
             best = max(ok, key=lambda k: table[k]["img_per_s"])
             result["parity_mode"] = {"precision": best, "img_per_s": table[best]["img_per_s"],
+                                     "encoder_mfma_frac": table[best]["encoder_mfma_frac"],
+                                     "gemm_family": table[best].get("gemm_family"), "kernels": table[best].pop("kernels", None),
                                      "logits_rel_max_vs_cpu_oracle": table[best]["logits_rel_max_vs_cpu_oracle"],
+                                     "logits_rel_l2_vs_cpu_oracle": table[best]["logits_rel_l2_vs_cpu_oracle"],
                                      "note": "fastest precision whose FullModel logits are within BASELINE.json's 1e-3 of the CPU fp32 oracle "
                                              f"(first {n_ref} images, {args.classes} classes); the headline `value` is the bf16 mode BASELINE configs[1] names"}
     if world > 1:

@@ -166,7 +166,9 @@ int tapclip_logits_backward(const float* grad_logits, const float* logits, const
  * reference models/prompt_learner.py:32-33 calls token_embedding alone: add_pos = 0).
  * tokens [n,L] int64 -> out [n,L,D] fp32.  An id outside [0, vocab) returns TAPCLIP_EINVAL (torch's
  * embedding raises there too); to report it this entry point WAITS for the stream -- it is off the
- * hot path (prompt construction, encode_text) and must not be captured into a graph. */
+ * hot path (prompt construction, encode_text) and must not be captured into a graph.
+ * ONE caller at a time per tower handle: the out-of-range flag is a single word owned by the handle, so two
+ * streams calling this on the same handle concurrently would share (and clear) each other's flag. */
 int tapclip_embed_tokens(tapclip_tower_t* text, const int64_t* tokens, int32_t n_seq, int32_t len,
                          int32_t add_pos, float* out, tapclip_stream_t stream);
 

@@ -108,7 +108,7 @@ def _rq(x: torch.Tensor, emulate: Optional[str]) -> torch.Tensor:
     """Rounding of a block-GEMM operand (k = last dim): MXFP8 on the fp8 path (oracle/mx8_ref.py), else as _rb."""
     if emulate == "mx8":
         from . import mx8_ref
-        return mx8_ref.fake_quant(x)
+        return mx8_ref.fake_quant(x).to(x.dtype)  # (exact in fp32; back to x's dtype: the emulation also runs in float64)
     return _rb(x, emulate)
 
 

@@ -155,9 +155,23 @@ def g_image_tower(ref):
         cfg = clip_ref.CONFIGS[name]
         sd = synth.make_state_dict(cfg, seed=2, text=False)
         images = synth.make_images(2, cfg, 0)
+        extra = {}
         with torch.no_grad():
             emb = clip_ref.encode_image(images, sd, cfg)
-        _save(f"image_tower_{name}", seed_weights=2, seed_images=0, batch=2, embeddings=emb)
+            if name == "ViT-B-16":
+                extra = _mx8_pair(images, sd, cfg)
+        _save(f"image_tower_{name}", seed_weights=2, seed_images=0, batch=2, embeddings=emb, **extra)
+
+
+def _mx8_pair(images, sd, cfg):
+    """The oracle with the block GEMMs' operands rounded to MXFP8 at the kernels' rounding points, accumulating in fp32
+    and in fp64: the distance between the two is the floor of agreement for ANY two implementations of that pipeline
+    (as clip_ref.emulation_floor is for bf16) -- the fp8 tests hold the HIP tower to 1.5x it instead of a loose constant."""
+    e32 = clip_ref.encode_image(images, sd, cfg, emulate="mx8")
+    e64 = clip_ref.encode_image(images.double(), {k: v.double() for k, v in sd.items()}, cfg, emulate="mx8")
+    floor = float((e32.double() - e64).norm() / e64.norm())
+    print(f"  mx8 emulation floor (fp32 vs fp64 accumulation) {floor:.3e}")
+    return dict(embeddings_mx8=e32, embeddings_mx8_f64=e64.float(), mx8_floor_rel_l2=floor)
 
 
 def _seed_context(model, class_names, cfg, prompt_len, seed):
@@ -223,9 +237,9 @@ def g_image_tower_l14(ref):
     with torch.no_grad():
         t0 = time.time()
         emb = clip_ref.encode_image(images, sd, cfg)
-        emb8 = clip_ref.encode_image(images, sd, cfg, emulate="mx8")
+        pair = _mx8_pair(images, sd, cfg)
     print(f"  {time.time() - t0:.0f}s")
-    _save("image_tower_ViT-L-14-336", seed_weights=2, seed_images=0, batch=2, embeddings=emb, embeddings_mx8=emb8)
+    _save("image_tower_ViT-L-14-336", seed_weights=2, seed_images=0, batch=2, embeddings=emb, **pair)
 
 
 def g_fullmodel_l14(ref):

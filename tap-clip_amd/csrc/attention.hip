@@ -632,3 +632,4 @@ hipError_t launch_head_mean(const float* probs, int32_t n, int32_t H, int32_t T,
 }
 
 }  // namespace tapclip
+TAPCLIP_TU_NO_PK_F32_END

@@ -99,6 +99,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 #ifndef TAPCLIP_GELU_TR
 #define TAPCLIP_GELU_TR 0
 #endif
+// experiment switches (tools/gemm_bench_alt; none is set in the library build)
+#ifndef TAPCLIP_X_PRIO
+#define TAPCLIP_X_PRIO 0        // 1: s_setprio 1 around the MFMA cluster; 2: around the READ phase
+#endif
+#ifndef TAPCLIP_X_READ_FIRST
+#define TAPCLIP_X_READ_FIRST 0  // 1: the fragment reads are issued before the DMA of step h + NS - 1
+#endif
+#ifndef TAPCLIP_EPI_EARLY_B
+#define TAPCLIP_EPI_EARLY_B 1  // group B's epilogue in the same phase as group A's (see the tile boundary below)
+#endif
   constexpr bool TR_EPI = !SPLIT && (EPI == EPI_BIAS_BF16 || (TAPCLIP_GELU_TR && EPI == EPI_BIAS_GELU_BF16));
   constexpr int ROW_CHUNKS = BN / 32;     // 16-B chunks per 16-row scratch row (wave covers BN/4 columns)
   // The GELU epilogue stores straight from the accumulators, but with the W rows of each PAIR of 16-wide
@@ -266,9 +276,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 
   int st = 0;        // ring stage of the step being computed
   int relaxed = 0;   // waits for which the previous epilogue's NST stores may still be in flight
-  bool pending = false;  // a finished tile's accumulators wait for their epilogue
-  int64_t m0 = 0, em0 = 0;
-  int n0 = 0, en0 = 0;
+  int64_t m0 = 0;
+  int n0 = 0;
   f32x4_t acc[NJ][8];
 
   auto wait_dma = [&](bool issued) {
@@ -282,6 +291,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
   };
 
   auto epilogue = [&](int64_t m0, int n0) {
+    // The lane id is re-derived behind an opaque asm so that the epilogue's per-lane address arithmetic is computed
+    // here, once per tile, instead of being hoisted out of the tile loop and held in VGPRs across the k-loop
+    // (with 128 accumulator + 48 fragment registers live there the hoisted values were spilled, and a scratch
+    // reload is a vector-memory load: the compiler drains vmcnt -- the whole DMA ring -- in front of it).
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int lane = lane_e, r = lane_e & 15, q = lane_e >> 4;
     if (TR_EPI) {
       // lane (r, q) holds, per 16-row block i and sub-tile j, 4 consecutive n of row 16 i + r.  Write the
       // block as [16 rows][BN/4 bf16] (16-B chunk c of row rr at slot c ^ (rr & 7): conflict-free both
@@ -468,65 +484,93 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
     const int ks_begin = cur_partial ? split_part * KSP : 0;
     const int ks_end = cur_partial ? ks_begin + KSP : KS;
 
+    // accumulators start at the bias (lane holds n = n0 + wn * BN/4 + 16 j + 4 q + e for every m)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(bias_lds + n0 + wn * (BN / 4) + col_of(j));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[j][i] = (EPI == EPI_PATCH_F32 || cur_partial) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : bv;
+    }
+
     for (int ks = ks_begin; ks < ks_end; ++ks) {
       // ================= READ phase
-      if (ks == ks_begin) {
-        if (pending) {
-          epilogue(em0, en0);  // (a pending tile is never a partial one: the K-split part is a workgroup's last item)
-          // exactly NST stores were issued and the cursor is still issuing: the next NS-2 waits may skip them
-          relaxed = (CLEAN_EPI && f_valid && (em0 + BM <= g.M)) ? NS - 2 : 0;
-          pending = false;
-        }
-        // accumulators start at the bias (lane holds n = n0 + wn * BN/4 + 16 j + 4 q + e for every m)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(bias_lds + n0 + wn * (BN / 4) + col_of(j));
-#pragma unroll
-          for (int i = 0; i < 8; ++i) acc[j][i] = (EPI == EPI_PATCH_F32 || cur_partial) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : bv;
-        }
-      }
       // stage (st + NS - 1) % NS: its last readers (group B, one phase ago) passed the previous barrier
       const bool issued = f_valid;
+#if TAPCLIP_X_PRIO == 2
+      __builtin_amdgcn_s_setprio(1);
+#endif
+#if !TAPCLIP_X_READ_FIRST
       if (issued) fetch_next((st + NS - 1) % NS);
+#endif
       const uint8_t* base = smem + st * STAGE;
       bf16x8_t wf[NJ], af[8];
 #pragma unroll
       for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(base + w_base + w_sub_off(j));
 #pragma unroll
       for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(base + a_base + i * 1024);
+#if TAPCLIP_X_READ_FIRST
+      if (issued) fetch_next((st + NS - 1) % NS);
+#endif
       if (grp_b) wait_dma(issued);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers: the stage may be reused
+#if TAPCLIP_X_PRIO == 2
+      __builtin_amdgcn_s_setprio(0);
+#endif
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       // ================= COMPUTE phase
+#if TAPCLIP_X_PRIO == 1
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[j][i] = TAPCLIP_MFMA_16x16x32(wf[j], af[i], acc[j][i]);
+#if TAPCLIP_X_PRIO == 1
+      __builtin_amdgcn_s_setprio(0);
+#endif
       if (!grp_b) wait_dma(issued);
+      st = (st + 1) % NS;
+      if (ks != ks_end - 1) {  // (the barrier behind a tile's last COMPUTE phase is placed around the epilogue, below)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+    }
+    // ================= tile boundary: the finished tile's epilogue, ONE call site for both groups.
+    // Group A passes the phase barrier first -- its epilogue opens what is its READ phase of the next tile's step 0.
+    // Group B runs the epilogue straight behind its last COMPUTE phase, BEFORE that barrier: in the same phase as
+    // group A's, so that the two waves of a SIMD do their epilogue VALU work (GELU, packing) and stores side by
+    // side -- one wave alone issues a VALU op every 4 cycles, two together one every 2 -- instead of one after the
+    // other with the partner parked at the barrier (two epilogue lengths per tile with the matrix pipe idle).
+    // vmcnt bookkeeping is the same for both groups: the NST stores sit between the DMA of steps h + NS - 2 and
+    // h + NS - 1 in issue order, so the next NS - 2 waits may leave them in flight.
+    if (!TAPCLIP_EPI_EARLY_B || !grp_b) {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      st = (st + 1) % NS;
     }
-    pending = true;
-    em0 = m0;
-    en0 = n0;
+    if (cur_partial) {
+      // K-split part (always a workgroup's last item): raw fp32 accumulators (no bias, no activation) ->
+      // split_ws[slot][256][BN]
+      float* dst = g.split_ws + (size_t)((split_lid - g.split_from) * g.split_parts + split_part) * (BM * BN);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          *reinterpret_cast<f32x4_t*>(dst + (wm * 128 + i * 16 + r) * BN + wn * (BN / 4) + col_of(j)) = acc[j][i];
+    } else {
+      epilogue(m0, n0);
+      // exactly NST stores were issued and the cursor is still issuing: the next NS-2 waits may skip them
+      relaxed = (CLEAN_EPI && f_valid && (m0 + BM <= g.M)) ? NS - 2 : 0;
+    }
+    if (TAPCLIP_EPI_EARLY_B && grp_b) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
     if (!has_next) break;
     lid = next_lid;
     cur_partial = next_partial;
   }
-  // the last item's epilogue; group A is one phase ahead and owes the barrier group B started with
-  if (cur_partial) {
-    // K-split part: raw fp32 accumulators (no bias, no activation) -> split_ws[slot][256][BN]
-    float* dst = g.split_ws + (size_t)((split_lid - g.split_from) * g.split_parts + split_part) * (BM * BN);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        *reinterpret_cast<f32x4_t*>(dst + (wm * 128 + i * 16 + r) * BN + wn * (BN / 4) + col_of(j)) = acc[j][i];
-  } else {
-    epilogue(em0, en0);
-  }
+  // group A is one phase ahead and owes the barrier group B started with
   if (!grp_b) __builtin_amdgcn_s_barrier();
 }
 
@@ -670,3 +714,4 @@ hipError_t launch_gemm256(const GemmArgs& a, int epilogue, bool split, hipStream
 }
 
 }  // namespace tapclip
+TAPCLIP_TU_NO_PK_F32_END

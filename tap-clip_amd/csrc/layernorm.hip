@@ -30,7 +30,11 @@ namespace {
 //   runs on it: one pass over the patch embeddings instead of an in-place fp32 ln_pre followed by a second kernel.
 __device__ __forceinline__ uint32_t x24_bits(float v) {  // fp32 bits rounded to nearest-even at bit 8
   const uint32_t u = __float_as_uint(v);
-  return u + 0x7Fu + ((u >> 8) & 1u);
+  const uint32_t r = u + 0x7Fu + ((u >> 8) & 1u);
+  // exponent all ones: no rounding add (it would carry an all-ones-mantissa NaN over into -0.0 / +0.0), and a NaN whose
+  // payload sits in the 8 dropped bits gets its quiet bit set, so that a NaN in the residual stays a NaN in the planes
+  const bool special = (u & 0x7F800000u) == 0x7F800000u;
+  return special ? (u | ((u & 0x007FFFFFu) ? 0x00400000u : 0u)) : r;
 }
 typedef uint32_t ln_u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void x24_store(bf16_t* hi, uint8_t* lo, const float4& v) {

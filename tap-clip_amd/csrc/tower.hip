@@ -298,6 +298,7 @@ int group_m_for(int slot) {
   static const bool init = [] {
     const char* e = getenv("TAPCLIP_GM");
     if (e) sscanf(e, "%d,%d,%d,%d", &gm[0], &gm[1], &gm[2], &gm[3]);
+    for (int& v : gm) v = v < 1 ? 1 : v;  // the tile order divides by it
     return true;
   }();
   (void)init;
@@ -315,6 +316,7 @@ int group_m_mx8_for(int slot) {  // the same for the MXFP8 GEMM (TAPCLIP_GM8="q,
   static const bool init = [] {
     const char* e = getenv("TAPCLIP_GM8");
     if (e) sscanf(e, "%d,%d,%d,%d", &gm[0], &gm[1], &gm[2], &gm[3]);
+    for (int& v : gm) v = v < 1 ? 1 : v;
     return true;
   }();
   (void)init;
@@ -327,11 +329,24 @@ int group_m_mx8_for(int slot) {  // the same for the MXFP8 GEMM (TAPCLIP_GM8="q,
   }
 }
 
+// Bisection aids (TAPCLIP_DEBUG_SYNC=<mask>: stream sync after LN (1) / GEMM (2) / attention (4) launches;
+// TAPCLIP_DEBUG_STOP=<k>: run_blocks returns early, leaving an UNFINISHED residual) exist only in builds made with
+// -DTAPCLIP_DEBUG_KNOBS (tools/dbg_ws2.py): an environment variable must not be able to make the shipped library
+// return TAPCLIP_OK with a half-computed result.
+#ifdef TAPCLIP_DEBUG_KNOBS
 int dbg_sync_mask() {
   static const int m = [] { const char* e = getenv("TAPCLIP_DEBUG_SYNC"); return e ? atoi(e) : 0; }();
   return m;
 }
+int dbg_stop_at() {
+  static const int m = [] { const char* e = getenv("TAPCLIP_DEBUG_STOP"); return e ? atoi(e) : 0; }();
+  return m;
+}
 #define DBG_SYNC(bit, s) do { if (dbg_sync_mask() & (bit)) (void)hipStreamSynchronize(s); } while (0)
+#else
+constexpr int dbg_stop_at() { return 0; }
+#define DBG_SYNC(bit, s) do { } while (0)
+#endif
 
 int gemm(tapclip_tower* t, int slot, int epi, const bf16_t* a_hi, const bf16_t* a_lo, int64_t lda, const Packed& w,
          const float* bias, int64_t M, int N, int K, bf16_t* o_hi, bf16_t* o_lo, float* o_f32, int64_t ldo,
@@ -439,7 +454,7 @@ int run_blocks(tapclip_tower* t, float* x, int64_t n_seq, int tokens, int causal
       else HIP_TRY(launch_add_layernorm_ex(3, x, w.a_hi, w.a_lo, w.d_hi, w.d_lo, L.ln1_g, L.ln1_b, M, D, w.xn_hi, w.xn_lo, s, stream_x));
       DBG_SYNC(1, s);
     }
-    static const int dbg_stop = [] { const char* e = getenv("TAPCLIP_DEBUG_STOP"); return e ? atoi(e) : 0; }();
+    const int dbg_stop = dbg_stop_at();
     if (dbg_stop == 1 && li == 1) return TAPCLIP_OK;
     if (dbg_stop == 5 && li == 0) return TAPCLIP_OK;  // (3, 4, 5: block 0 after its first LayerNorm / LN2 / c_fc -- tools/dbg_ws2.py)
     int rc = gemm(t, 2, EPI_BIAS_BF16, w.xn_hi, w.xn_lo, D, L.wqkv, L.bqkv, M, 3 * D, D, w.qkv_hi, w.qkv_lo, nullptr,

@@ -11,13 +11,38 @@ def is_distributed() -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
-def all_gather_rows(x: torch.Tensor, group=None, force: bool = False) -> torch.Tensor:
-    """[B_local, E] on every rank -> [world * B_local, E], rank-major rows.  Identity at world size 1 (`force=True`
-    still issues the collective on an initialised group of one rank: the RCCL call path on a 1-GPU box)."""
+def _row_counts(n_local: int, device, group=None):
+    """every rank's row count, as a python list (one tiny collective)"""
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo":
+        parts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(parts, torch.tensor([n_local], dtype=torch.int64), group=group)
+        return [int(p) for p in parts]
+    out = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, torch.tensor([n_local], dtype=torch.int64, device=device), group=group)
+    return [int(v) for v in out.tolist()]
+
+
+def all_gather_rows(x: torch.Tensor, group=None, force: bool = False, ragged: bool = False) -> torch.Tensor:
+    """[B_local, E] on every rank -> [sum of B_local, E], rank-major rows.  Identity at world size 1 (`force=True`
+    still issues the collective on an initialised group of one rank: the RCCL call path on a 1-GPU box).
+
+    `ragged=False` (the benchmarked hot path: the global batch is sharded evenly, `shard_rows`) gathers straight into
+    one tensor and REQUIRES the same row count on every rank -- unequal counts would hang RCCL.  `ragged=True` first
+    exchanges the row counts (one 8-byte collective), pads every shard to the longest and drops the padding after the
+    gather: the last, short batch of an evaluation loader that is sharded without padding (drop_last=False)."""
     if not (is_distributed() or (force and dist.is_available() and dist.is_initialized())):
         return x
     x = x.contiguous()
     world = dist.get_world_size(group)
+    if ragged:
+        counts = _row_counts(x.shape[0], x.device, group)
+        longest = max(counts)
+        if any(c != longest for c in counts):
+            pad = torch.zeros((longest - x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+            full = all_gather_rows(torch.cat([x, pad], dim=0), group=group, force=force, ragged=False)
+            keep = torch.cat([torch.arange(r * longest, r * longest + c) for r, c in enumerate(counts)]).to(full.device)
+            return full.index_select(0, keep)
     if dist.get_backend(group) == "gloo":
         # CPU rehearsal backend (tests; several ranks sharing one GPU): stage through host memory
         parts = [torch.empty(x.shape, dtype=x.dtype) for _ in range(world)]

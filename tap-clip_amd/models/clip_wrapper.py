@@ -9,9 +9,12 @@ under open_clip's names so `state_dict()` / `load_state_dict()` keep the referen
 (`clip.model.*`, reference test_cross_domain.py:43-61).
 
 Extra keyword-only knobs (defaults keep behaviour):
-  precision       "bf16" (fast) | "bf16x3" (split-bf16, ~fp32 accuracy: the parity mode) |
-                  "fp16" (the fast mode INSIDE BASELINE.json's 1e-3 bound: image tower on the IEEE-half build of the
-                  same kernels -- bf16 speed, 2.8e-4 embedding error -- text tower split-bf16) |
+  precision       "fp16" (THE DEFAULT: the fast mode INSIDE BASELINE.json's 1e-3 bound on embeddings and logits -- image
+                  tower on the IEEE-half build of the same kernels at 97 % of the bf16 mode's speed, 2.8e-4 embedding
+                  error; text tower split-bf16, forward and backward.  The reference is fp32 end to end, reference
+                  models/model_wrapper.py:73-79, so the drop-in default is the mode that matches it) |
+                  "bf16" (fastest 16-bit mode, the one BASELINE configs[1] names: 1-2e-2 on logits) |
+                  "bf16x3" (split-bf16 everywhere, ~fp32 accuracy at a third of the speed) |
                   "fp8" (image tower block GEMMs on MXFP8 MFMA, text tower bf16; a throughput mode:
                   ~4 % error per GEMM)
   attn_semantics  "intended": the text hook yields the head-mean softmax map [n,T,T] that the
@@ -79,8 +82,10 @@ class _TextTransformer(_Bag):
 
     def capture(self, x: torch.Tensor) -> None:
         """The call of reference models/model_wrapper.py:58: the transformer is run for the hook's capture only and its
-        output is discarded -- so the last block stops after its attention."""
-        self.forward(x, _need_hidden=False)
+        output is discarded -- so the last block stops after its attention.  Routed through nn.Module.__call__ like
+        the reference's `clip.model.transformer(prompts)`, so forward / pre-forward hooks a user registered on
+        `clip.model.transformer` fire for this pass too (they see `None` as the output: there is no hidden state)."""
+        self(x, _need_hidden=False)
 
     def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None, _need_hidden: bool = True) -> torch.Tensor:
         own = self._owner
@@ -187,7 +192,7 @@ def _make_preprocess(size: int) -> Callable:
 
 class CLIPWrapper(nn.Module):
     def __init__(self, model_name: str = "ViT-B-32", pretrained_path: Optional[str] = "path/to/open_clip_pytorch_model.bin",
-                 device: str = "cuda", *, precision: str = "bf16", attn_semantics: str = "intended",
+                 device: str = "cuda", *, precision: str = "fp16", attn_semantics: str = "intended",
                  state_dict: Optional[Dict[str, torch.Tensor]] = None, config: Optional[ClipDims] = None,
                  bpe_path: Optional[str] = None, tokenizer=None):
         super().__init__()

@@ -90,6 +90,11 @@ class FullModel(nn.Module):
         self.logit_scale = nn.Parameter(torch.ones([]) * math.log(1 / 0.07))
         self.collapse_text = collapse_text
         self.gather_images = gather_images
+        # gather_images with UNEQUAL local batches (the short last batch of an evaluation loader sharded without padding):
+        # row counts are exchanged first and the shards padded for the collective (dist.all_gather_rows(ragged=True)).
+        # Off in the hot path -- evenly sharded batches need no extra collective; the evaluation helpers of
+        # utils/eval_metrics.py switch it on for their loops.
+        self.ragged_batches = False
         # The image tower does not depend on the text side: it is launched on a second HIP stream so that its
         # chip-filling kernels run beside the text tower's small grids (65 x 93 rows: 96-192 workgroups per GEMM
         # on 256 CUs) instead of after them.
@@ -238,9 +243,9 @@ class FullModel(nn.Module):
             labels = labels.to(image_feat.device)
         if self.gather_images:
             from ..dist import all_gather_rows
-            image_feat = all_gather_rows(image_feat)
+            image_feat = all_gather_rows(image_feat, ragged=self.ragged_batches)
             if labels is not None:
-                labels = all_gather_rows(labels)
+                labels = all_gather_rows(labels, ragged=self.ragged_batches)
         return image_feat, labels
 
     def forward(self, images, labels=None):

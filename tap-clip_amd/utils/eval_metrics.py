@@ -12,17 +12,42 @@ import torch
 
 @torch.no_grad()
 def _count(model, dataloader, device):
+    """Per-class (correct, total) counts over the loader.
+
+    Data-parallel FullModel (`gather_images=True`): every rank holds the GLOBAL logits (rank-major rows), so the rank's
+    labels are gathered the same way and every rank counts the same global totals.  Local batches may differ in length
+    (an evaluation loader sharded without padding ends in a short batch on some ranks): embeddings and labels are
+    gathered with their row counts exchanged first (`dist.all_gather_rows(ragged=True)`).  Ranks must still run the same
+    NUMBER of batches -- a rank whose shard is exhausted early must feed empty batches -- and a sampler that pads its
+    shards with DUPLICATE samples (torch's DistributedSampler with drop_last=False) has those duplicates counted: shard
+    without padding (e.g. indices[rank::world]) to get the single-process figures."""
     model.eval()
+    correct = total = None
+    gather = bool(getattr(model, "gather_images", False))
+    was_ragged = getattr(model, "ragged_batches", False)
+    if gather:
+        model.ragged_batches = True
+    try:
+        correct, total = _count_loop(model, dataloader, device, gather)
+    finally:
+        if gather:
+            model.ragged_batches = was_ragged
+    return correct, total
+
+
+def _count_loop(model, dataloader, device, gather):
     correct = total = None
     for images, labels in dataloader:
         images, labels = images.to(device), labels.to(device)
         logits = model(images)["logits"]
         n_cls = logits.shape[1]
-        if getattr(model, "gather_images", False):
-            # data-parallel FullModel: every rank holds the GLOBAL logits (rank-major rows), so the rank's labels are
-            # gathered the same way and every rank counts the same global totals
+        if gather:
             from ..dist import all_gather_rows
-            labels = all_gather_rows(labels)
+            labels = all_gather_rows(labels, ragged=True)
+            if labels.shape[0] != logits.shape[0]:
+                raise RuntimeError(f"gathered {labels.shape[0]} labels for {logits.shape[0]} logit rows: ranks disagree on the batch")
+        if labels.numel() == 0:
+            continue
         preds = torch.argmax(logits, dim=1)
         hit = (preds == labels).to(torch.int64)
         size = max(n_cls, int(labels.max()) + 1) if correct is None else max(n_cls, correct.numel(), int(labels.max()) + 1)

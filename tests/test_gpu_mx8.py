@@ -159,7 +159,18 @@ def test_fp8_encode_image_vitb16(eng):
     rel = float((a - ref).norm() / ref.norm())
     cos = torch.nn.functional.cosine_similarity(a, ref, dim=-1)
     print(f"[fp8 ViT-B/16] vs fp32 golden: rel_l2 {rel:.3e}, cosine min {float(cos.min()):.5f} mean {float(cos.mean()):.5f}")
-    assert rel < 0.15 and float(cos.min()) > 0.99
+    # Floor-based bounds (the loose 0.15 / 0.99 would have passed a broken scale plane in one layer).
+    # The oracle with MXFP8 operand rounding at the kernels' rounding points, run with fp32 and with fp64 accumulation,
+    # disagrees with ITSELF by `mx8_floor_rel_l2` (2.4e-2 over 12 blocks: rounding-boundary flips of whole e4m3 steps,
+    # amplified block by block) -- the closest any two implementations of this pipeline can agree.  The HIP tower is held
+    # to 1.5x that floor against the fp64-accumulating emulation, and to 1.5x the FORMAT's own error (that emulation
+    # against the fp32 oracle, 3.8e-2) against the fp32 golden.
+    emu64, floor = torch.from_numpy(g["embeddings_mx8_f64"]), float(g["mx8_floor_rel_l2"])
+    fmt = float((emu64 - ref).norm() / ref.norm())
+    e_emu = float((a - emu64).norm() / emu64.norm())
+    print(f"[fp8 ViT-B/16] vs MXFP8 emulation (fp64 acc): rel_l2 {e_emu:.3e}; floor {floor:.3e}; format error {fmt:.3e}")
+    assert e_emu < 1.5 * floor, (e_emu, floor)
+    assert rel < 1.5 * fmt and float(cos.min()) > 0.998, (rel, fmt, float(cos.min()))
     one = tower.encode_image(images[:1].to(DEV)).cpu()   # M = 197: a single ragged row tile
     assert float((one - a[:1]).norm() / a[:1].norm()) < 1e-6
 

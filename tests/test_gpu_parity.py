@@ -29,6 +29,12 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 TOL_EMU = 2e-3
 TOL_BF16 = 2e-2
+# Two bf16-operand evaluations of ONE image that associate their fp32 sums differently (the K-split tail tiles of
+# gemm256.hip): each sits one emulation floor -- 1.1e-3 rel-L2 per ViT-B block (clip_ref.emulation_floor,
+# tests/test_oracle.py::test_emulation_floor_of_chained_bf16_rounding), 2.4e-3 on the L2-normalised embedding after 12
+# blocks -- from the exact value with independent roundings, i.e. sqrt(2) x 2.4e-3 = 3.4e-3 from each other.  A fixed
+# bound (it used to follow the run's own measured error); measured 2.1e-3.
+TOL_TAIL_SPLIT = 3.5e-3
 DEV = "cuda:0"
 
 
@@ -289,10 +295,9 @@ def test_encode_image_full_batch_properties(eng, vitb16):
     assert own < TOL_BF16
     # the last row tiles of the N = 768, K = 3072 GEMM are K-split over the CUs a partial round would idle
     # (gemm256.hip "tail split"): their fp32 sums associate differently, so those rows match a small batch
-    # to the mode's round-off instead of bitwise -- two roundings of one computation (bf16 operands, half residual
-    # stream) differ by less than 1.5x what either is off the exact result (measured 2.1e-3 against 2.4e-3)
+    # to the mode's round-off instead of bitwise (TOL_TAIL_SPLIT above; README "known properties of the bf16 mode")
     last = tower.encode_image(images[-8:].clone(), normalize=True)
-    assert rel_l2(last.cpu(), a[-8:].cpu()) < 1.5 * own
+    assert rel_l2(last.cpu(), a[-8:].cpu()) < TOL_TAIL_SPLIT
 
 
 # ---- text side ----------------------------------------------------------------------------------

@@ -61,6 +61,14 @@ logits = 14.2857 * gathered @ txt.t()
 assert torch.allclose(logits, 14.2857 * full @ txt.t())
 labels = torch.arange(8) * 3 % 5                                               # int64 labels travel the same way
 assert torch.equal(all_gather_rows(labels[lo:hi].clone()), labels)
+# ragged shards (the short last batch of an evaluation loader sharded without padding): 5 + 3 rows, then 2 + 0 rows
+cut = 5
+mine = full[:cut] if rank == 0 else full[cut:]
+assert torch.equal(all_gather_rows(mine.clone(), ragged=True), full)
+assert torch.equal(all_gather_rows((labels[:cut] if rank == 0 else labels[cut:]).clone(), ragged=True), labels)
+mine = full[:2] if rank == 0 else full[:0]
+assert torch.equal(all_gather_rows(mine.clone(), ragged=True), full[:2])
+assert torch.equal(all_gather_rows(full[lo:hi].clone(), ragged=True), full)    # equal shards: same result as the plain path
 dist.barrier(); dist.destroy_process_group()
 print("ok", rank)
 """
@@ -75,6 +83,22 @@ def test_all_gather_two_ranks_gloo(tmp_path):
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus N` with WORLD_SIZE unset -- the form the driver uses for N = 1 -- must start its N ranks
+    itself (it exited with "launch N>1 with ...").  No GPU here: every rank stops at bench.py's "needs an
+    MI355X" check, which is what this test looks for -- reached through torch.distributed.run, with the
+    parent relaying the launcher's non-zero exit code instead of raising itself."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: the 4-rank run of tests/test_gpu_configs.py covers the path")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert "starting 8 ranks" in r.stderr and "torch.distributed.run" in r.stderr, r.stderr[-2000:]
+    # (the launcher stops the other ranks as soon as one has failed: between 1 and 8 of them get to say it)
+    assert 1 <= r.stderr.count("bench.py needs an MI355X") <= 8, r.stderr[-3000:]
+    assert r.returncode != 0 and "launch N>1 with" not in r.stderr
 
 
 def test_image_folder_few_shot_loaders(tmp_path):

@@ -70,7 +70,14 @@ int main(int argc, char** argv) {
       {"qkv-like N2304 K3072 bias->bf16 ", 2304, 3072, EPI_BIAS_BF16},   // slope/intercept probe
       {"qkv-like N2304 K1536 bias->bf16 ", 2304, 1536, EPI_BIAS_BF16},
   };
-  const Shape* shapes = text ? text_shapes : image_shapes;
+  const Shape* all_shapes = text ? text_shapes : image_shapes;
+  // argv[4] / $GEMM_BENCH_ONLY: only the shapes whose label contains this substring (profiling one kernel family)
+  const char* only = argc > 4 ? argv[4] : getenv("GEMM_BENCH_ONLY");
+  std::vector<Shape> picked;
+  for (int k = 0; k < (text ? (int)(sizeof(text_shapes) / sizeof(text_shapes[0])) : (int)(sizeof(image_shapes) / sizeof(image_shapes[0]))); ++k)
+    if (!only || strstr(all_shapes[k].name, only)) picked.push_back(all_shapes[k]);
+  if (picked.empty()) { printf("no shape matches %s\n", only); return 1; }
+  const Shape* shapes = picked.data();
   bf16_t* A = rand_bf16((size_t)M * 3072, 1, 1.0f);
   bf16_t* W = rand_bf16((size_t)3072 * 3072, 2, 0.03f);
   float* bias;
@@ -89,7 +96,7 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   // interleaved rounds in ONE process (guide rule 24): every round times each shape once; report median / min
-  const int n_shapes = text ? (int)(sizeof(text_shapes) / sizeof(text_shapes[0])) : (int)(sizeof(image_shapes) / sizeof(image_shapes[0]));
+  const int n_shapes = (int)picked.size();
   std::vector<std::vector<float>> times(n_shapes);
   auto run = [&](const Shape& sh, int reps) {
     GemmArgs g;
@@ -118,7 +125,8 @@ int main(int argc, char** argv) {
     }
   }
   // ---- attention core at the image tower's shape (buffers are sized for M = 50 432: not in the text mode)
-  if (!text && M >= 64 * 577) {
+  const bool with_attn = !only || strstr("attention", only);
+  if (!text && M >= 64 * 577 && with_attn) {
     AttnArgs a;
     a.qkv_hi = A; a.qkv_lo = nullptr; a.out_hi = obf; a.out_lo = nullptr; a.probs = nullptr;
     a.n_seq = (int)(M / 197); a.T = 197; a.H = 12; a.D = 768; a.causal = 0;
@@ -136,7 +144,7 @@ int main(int argc, char** argv) {
     std::sort(t.begin(), t.end());
     printf("attention n%d T197 H12: median %8.1f us  min %8.1f us\n", a.n_seq, 1e3 * t[t.size() / 2], 1e3 * t[0]);
   }
-  if (!text && M >= 64 * 577) {  // ViT-L/14@336 attention: 577 tokens, 16 heads (flash-style kernel)
+  if (!text && M >= 64 * 577 && with_attn) {  // ViT-L/14@336 attention: 577 tokens, 16 heads (flash-style kernel)
     AttnArgs a;
     a.qkv_hi = A; a.qkv_lo = nullptr; a.out_hi = obf; a.out_lo = nullptr; a.probs = nullptr;
     a.n_seq = 64; a.T = 577; a.H = 16; a.D = 1024; a.causal = 0;
