@@ -99,13 +99,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 #ifndef TAPCLIP_GELU_TR
 #define TAPCLIP_GELU_TR 0
 #endif
-// experiment switches (tools/gemm_bench_alt; none is set in the library build)
-#ifndef TAPCLIP_X_PRIO
-#define TAPCLIP_X_PRIO 0        // 1: s_setprio 1 around the MFMA cluster; 2: around the READ phase
-#endif
-#ifndef TAPCLIP_X_READ_FIRST
-#define TAPCLIP_X_READ_FIRST 0  // 1: the fragment reads are issued before the DMA of step h + NS - 1
-#endif
 #ifndef TAPCLIP_EPI_EARLY_B
 #define TAPCLIP_EPI_EARLY_B 1  // group B's epilogue in the same phase as group A's (see the tile boundary below)
 #endif
@@ -496,39 +489,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
       // ================= READ phase
       // stage (st + NS - 1) % NS: its last readers (group B, one phase ago) passed the previous barrier
       const bool issued = f_valid;
-#if TAPCLIP_X_PRIO == 2
-      __builtin_amdgcn_s_setprio(1);
-#endif
-#if !TAPCLIP_X_READ_FIRST
       if (issued) fetch_next((st + NS - 1) % NS);
-#endif
       const uint8_t* base = smem + st * STAGE;
       bf16x8_t wf[NJ], af[8];
 #pragma unroll
       for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(base + w_base + w_sub_off(j));
 #pragma unroll
       for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(base + a_base + i * 1024);
-#if TAPCLIP_X_READ_FIRST
-      if (issued) fetch_next((st + NS - 1) % NS);
-#endif
       if (grp_b) wait_dma(issued);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers: the stage may be reused
-#if TAPCLIP_X_PRIO == 2
-      __builtin_amdgcn_s_setprio(0);
-#endif
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       // ================= COMPUTE phase
-#if TAPCLIP_X_PRIO == 1
-      __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[j][i] = TAPCLIP_MFMA_16x16x32(wf[j], af[i], acc[j][i]);
-#if TAPCLIP_X_PRIO == 1
-      __builtin_amdgcn_s_setprio(0);
-#endif
       if (!grp_b) wait_dma(issued);
       st = (st + 1) % NS;
       if (ks != ks_end - 1) {  // (the barrier behind a tile's last COMPUTE phase is placed around the epilogue, below)

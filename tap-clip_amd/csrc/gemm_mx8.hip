@@ -263,9 +263,8 @@ __global__ __launch_bounds__(512) void gemm_mx8_kernel(Mx8GemmArgs g) {
 #endif
   int st = 0;
   int relaxed = 0;
-  bool pending = false;
-  int64_t m0 = 0, em0 = 0;
-  int n0 = 0, en0 = 0;
+  int64_t m0 = 0;
+  int n0 = 0;
   f32x16_t acc[2][4];
 
   // The DMA of step h + NS - 1 is issued in the COMPUTE phase of step h, between the wave's own 64-cycle
@@ -405,26 +404,20 @@ __global__ __launch_bounds__(512) void gemm_mx8_kernel(Mx8GemmArgs g) {
     tile_origin(lid, m0, n0);
     const int next_lid = lid + bpx;
     const bool has_next = next_lid < chunk_hi;
+    // accumulators start at the bias
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      const float* bp = bias_lds + n0 + wn * 64 + (QOUT ? 32 * h + 16 * jt : 32 * jt + 16 * h);
+      f32x16_t bv;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) bv[e] = bp[e];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[jt][i] = bv;
+    }
     for (int ks = 0; ks < KS; ++ks) {
       // ================= READ phase
       STAMP(0);
       if (adv_pending) advance();  // (branchy cursor arithmetic: kept away from the MFMAs)
-      if (ks == 0) {
-        if (pending) {
-          epilogue(em0, en0);
-          relaxed = (CLEAN_EPI && em0 + BM <= g.M) ? NS - 2 : 0;
-          pending = false;
-        }
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt) {
-          const float* bp = bias_lds + n0 + wn * 64 + (QOUT ? 32 * h + 16 * jt : 32 * jt + 16 * h);
-          f32x16_t bv;
-#pragma unroll
-          for (int e = 0; e < 16; ++e) bv[e] = bp[e];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[jt][i] = bv;
-        }
-      }
       const uint8_t* base = smem + st * STAGE;
       u32x4_t wf[2][2], af[4][2];
       int wsc[2], asc[4];
@@ -470,22 +463,36 @@ __global__ __launch_bounds__(512) void gemm_mx8_kernel(Mx8GemmArgs g) {
       wait_dma(!grp_b);
       relaxed -= relaxed > 0 ? 1 : 0;
       STAMP(5);
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
+      st = (st + 1) % NS;
+      if (ks != KS - 1) {  // (the barrier behind a tile's last COMPUTE phase is placed around the epilogue, below)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
       STAMP(6);
 #ifdef MX8_STAMP
       ++stamp_n;
 #endif
-      st = (st + 1) % NS;
     }
-    pending = true;
-    em0 = m0;
-    en0 = n0;
+    // ================= tile boundary (as in gemm256.hip): ONE epilogue call site; group A passes the phase barrier
+    // first (its epilogue opens its READ phase of the next tile), group B runs the epilogue straight behind its last
+    // COMPUTE phase, before that barrier -- the two waves of a SIMD do their epilogue VALU work (GELU, re-quantisation,
+    // packing) side by side instead of one after the other with the partner parked at the barrier.  Group B's
+    // vector-memory ops keep their order (DMA of step h + NS - 1 in its COMPUTE phase, then the NST stores), so the
+    // wait counts are the ones of the previous placement.
+    if (!grp_b) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    epilogue(m0, n0);
+    relaxed = (CLEAN_EPI && m0 + BM <= g.M) ? NS - 2 : 0;
+    if (grp_b) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
     if (!has_next) break;
     lid = next_lid;
   }
-  epilogue(em0, en0);
-  if (!grp_b) __builtin_amdgcn_s_barrier();
+  if (!grp_b) __builtin_amdgcn_s_barrier();  // group A is one phase ahead and owes the barrier group B started with
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the cursor's surplus DMAs must land before the LDS is released
 #ifdef MX8_STAMP
   if (stamper)

@@ -2,7 +2,7 @@
 # Collects the round's profile set on the GPU box (run through gpurun from the repo root):
 #   tools/collect_profiles.sh <tag>     -> gpurun_out/prof_<tag>/..., summaries copied by hand into profiles/
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -18,6 +18,16 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- python3
 echo "write done"
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/sq -o sq -- python3 $R/bench.py $FAST > /dev/null 2> $OUT/sq.err
 echo "sq done"
+# BASELINE configs[4] at its per-GPU size, with a kept record: ViT-L/14@336, batch 128, each precision,
+# including full_forward and train_step (the reference loop being timed: train.py:95-105)
+for P in fp8 bf16 fp16; do
+  python3 $R/bench.py --model ViT-L-14-336 --batch 128 --precision $P --steps 20 --warmup 3 --no-cpu-baseline --no-input-side --no-precisions \
+    > $OUT/bench_${P}_vitl14_336_b128.json 2> $OUT/bench_${P}_vitl14_336_b128.err
+  echo "vit-l $P done"
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_l14 -o stats -- python3 $R/bench.py --model ViT-L-14-336 --batch 128 --precision fp8 --steps 10 --warmup 2 --no-cpu-baseline --no-input-side --no-precisions --no-full-forward > /dev/null 2> $OUT/stats_l14.err
+cp $(ls $OUT/stats_l14/*kernel_stats.csv $OUT/stats_l14/*/*kernel_stats.csv 2>/dev/null | head -n 1) $OUT/kernel_stats_bench_fp8_vitl14_336_b128.csv
+rm -rf $OUT/stats_l14
 cd $R
 python3 tools/trace_family.py $OUT/stats $OUT/gemm_family_trace_summary.json bf16
 python3 tools/pmc_traffic.py $OUT/fetch $OUT/write $OUT/pmc_traffic_bench.json

@@ -78,7 +78,8 @@ int main(int argc, char** argv) {
     if (!only || strstr(all_shapes[k].name, only)) picked.push_back(all_shapes[k]);
   if (picked.empty()) { printf("no shape matches %s\n", only); return 1; }
   const Shape* shapes = picked.data();
-  bf16_t* A = rand_bf16((size_t)M * 3072, 1, 1.0f);
+  const int lda_pad = getenv("GEMM_BENCH_LDA_PAD") ? atoi(getenv("GEMM_BENCH_LDA_PAD")) : 0;  // elements added to A's row stride
+  bf16_t* A = rand_bf16((size_t)M * (3072 + lda_pad), 1, 1.0f);
   bf16_t* W = rand_bf16((size_t)3072 * 3072, 2, 0.03f);
   float* bias;
   CK(hipMalloc(&bias, 3072 * 4));
@@ -100,7 +101,7 @@ int main(int argc, char** argv) {
   std::vector<std::vector<float>> times(n_shapes);
   auto run = [&](const Shape& sh, int reps) {
     GemmArgs g;
-    g.A_hi = A; g.A_lo = nullptr; g.lda = sh.K;
+    g.A_hi = A; g.A_lo = nullptr; g.lda = sh.K + lda_pad;
     g.W_hi = W; g.W_lo = nullptr;
     g.bias = bias;
     g.M = M; g.N = sh.N; g.K = sh.K;

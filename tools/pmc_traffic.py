@@ -45,6 +45,11 @@ def main():
             tot_b += (rd + wr) * n
             tot_n += n
     out["gemm_family_hbm_bytes_per_launch"] = round(tot_b / max(tot_n, 1))
+    # which kernel sources these passes measured: bench.py reports `traffic` only while the library is built from them
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import source_sha16
+    out["gemm_source_sha16"] = source_sha16()
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "kernels"}))
     for k, v in out["kernels"].items():
