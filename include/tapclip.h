@@ -232,6 +232,16 @@ int tapclip_mx8_gemm(const uint8_t* a_q, const uint8_t* a_scale, int64_t M, int6
                      int32_t epilogue, int32_t act, float* out_f32, uint8_t* out_q, uint8_t* out_q_scale,
                      tapclip_stream_t stream);
 
+/* ---- behaviour switches of a tower handle.
+ * TAPCLIP_FLAG_PRUNE_LAST_BLOCK (image towers, default 1; not the fp8 precision): `encode_image` returns the CLS row only
+ * (open_clip pools token 0 before ln_post / proj; reference call site models/clip_wrapper.py:46-47), so in the LAST block
+ * every other row's query, attention output, out_proj and MLP are dead work -- the reference computes them and throws
+ * them away.  With the flag on, the last block computes K and V for every token and the rest for the CLS rows only
+ * (same results to rounding: the CLS row's softmax and P.V run in fp32 there).  0 = compute every row of every block
+ * (what bench.py's headline `value` times: the full 35.127 GFLOP per ViT-B/16 image of SURVEY.md section 8d). */
+#define TAPCLIP_FLAG_PRUNE_LAST_BLOCK 1
+int tapclip_tower_set_flag(tapclip_tower_t* tower, int32_t flag, int32_t value);
+
 /* ---- per-stage timing (HIP events on `stream`) for bench.py's roofline object.
  * When enabled, tapclip_encode_image records events around each kernel family;
  * tapclip_profile_read (after a stream sync) returns accumulated ms and launch counts.

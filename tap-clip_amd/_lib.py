@@ -49,6 +49,7 @@ SYMBOLS = [
     ("tapclip_gemm_f32", _i32, [_p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _sz, _p]),
     ("tapclip_mx8_quantize", _i32, [_p, _i64, _i32, _p, _p, _i64, _p]),
     ("tapclip_mx8_gemm", _i32, [_p, _p, _i64, _i64, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
+    ("tapclip_tower_set_flag", _i32, [_p, _i32, _i32]),
     ("tapclip_profile_enable", _i32, [_p, _i32]),
     ("tapclip_profile_read", _i32, [_p, C.POINTER(_f32), C.POINTER(_i64)]),
     ("tapclip_last_error", C.c_char_p, []),
@@ -60,6 +61,7 @@ ACT_GELU_ERF, ACT_QUICK_GELU = 0, 1
 PREC_BF16, PREC_BF16X3, PREC_FP8 = 0, 1, 2
 # "fp16" is the bf16 code path of the IEEE-half build of the library
 PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp8": PREC_FP8, "fp16": PREC_BF16}
+FLAG_PRUNE_LAST_BLOCK = 1
 PROFILE_SLOTS = ("patch_embed", "layernorm", "gemm_qkv", "attention", "gemm_out_proj", "gemm_fc_gelu",
                  "gemm_proj", "pool_proj")
 

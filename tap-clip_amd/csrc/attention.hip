@@ -613,7 +613,138 @@ __global__ void head_mean_kernel(const float* __restrict__ probs, int H, int64_t
   out[i] = s / (float)H;
 }
 
+// ---- attention for ONE query row per sequence (the pooled token of a tower's LAST block).
+// The image tower's output is the CLS row only (open_clip pools token 0 before ln_post / proj; reference call site
+// models/clip_wrapper.py:46-47), so in the last block the other 196 rows' queries, attention outputs, out_proj and
+// MLP are dead work: K and V are still needed for every token, Q and everything behind the attention core only for the
+// pooled row (tower.hip run_last_block_pooled).  One wave per (sequence, head): lane l = 8 g + c works on dims
+// 8 c .. 8 c + 7 of token t0 + g, so a token's 128-B K / V row is ONE coalesced 8-lane access; the 8-lane dot
+// products are finished by three xor-shuffles, scores and probabilities live in LDS (T floats), softmax and P.V in
+// fp32 (no rounding of P: this path is more accurate than the full kernel, not bit-identical to it).
+// HBM-bound: it reads K and V of the layer once (2/3 of the q|k|v bytes the full kernel reads).
+struct AttnPoolArgs {
+  const bf16_t* q_hi;   // [n_seq, D] pooled queries (1/sqrt(64) folded into Wq)
+  const bf16_t* q_lo;   // bf16x3 only
+  const bf16_t* kv_hi;  // [n_seq * T, 3 D]: k at columns D + 64 h, v at 2 D + 64 h (the q columns are not read)
+  const bf16_t* kv_lo;
+  bf16_t* out_hi;       // [n_seq, D]
+  bf16_t* out_lo;
+  int32_t n_seq, T, H, D;
+};
+
+constexpr int POOL_MAX_T = 1024;
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void attn_pool_kernel(AttnPoolArgs a) {
+  __shared__ float sc[4][POOL_MAX_T];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + wave;  // (sequence, head)
+  if (item >= a.n_seq * a.H) return;
+  const int seq = item / a.H, h = item - seq * a.H;
+  const int g = lane >> 3, c = lane & 7;
+  const int64_t ld = 3 * (int64_t)a.D;
+  auto load8 = [&](const bf16_t* hi, const bf16_t* lo, int64_t off, float (&v)[8]) {
+    const uint4 u = *reinterpret_cast<const uint4*>(hi + off);
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[2 * j] = bf2f((bf16_t)(w[j] & 0xFFFF));
+      v[2 * j + 1] = bf2f((bf16_t)(w[j] >> 16));
+    }
+    if (SPLIT) {
+      const uint4 ul = *reinterpret_cast<const uint4*>(lo + off);
+      const uint32_t wl[4] = {ul.x, ul.y, ul.z, ul.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[2 * j] += bf2f((bf16_t)(wl[j] & 0xFFFF));
+        v[2 * j + 1] += bf2f((bf16_t)(wl[j] >> 16));
+      }
+    }
+  };
+  float q[8];
+  load8(a.q_hi, a.q_lo, (int64_t)seq * a.D + 64 * h + 8 * c, q);
+  const int64_t row0 = (int64_t)seq * a.T;
+  const int64_t kcol = a.D + 64 * h + 8 * c, vcol = 2 * (int64_t)a.D + 64 * h + 8 * c;
+  // ---- scores s_t = q . k_t, 8 tokens per iteration
+  float mx = -3.0e38f;
+#pragma unroll 4
+  for (int t0 = 0; t0 < a.T; t0 += 8) {
+    const int t = t0 + g;
+    float k[8];
+    float dot = 0.f;
+    if (t < a.T) {
+      load8(a.kv_hi, a.kv_lo, (row0 + t) * ld + kcol, k);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dot = fmaf(q[j], k[j], dot);
+    }
+    dot += __shfl_xor(dot, 1, 64);
+    dot += __shfl_xor(dot, 2, 64);
+    dot += __shfl_xor(dot, 4, 64);
+    if (t < a.T) {
+      if (c == 0) sc[wave][t] = dot;
+      mx = fmaxf(mx, dot);
+    }
+  }
+  mx = wave_max(mx);
+  __builtin_amdgcn_wave_barrier();
+  // ---- p_t = exp(s_t - max), sum (a wave's LDS accesses execute in order; the waves are independent)
+  float sum = 0.f;
+  for (int t = lane; t < a.T; t += 64) {
+    const float p = __expf(sc[wave][t] - mx);
+    sc[wave][t] = p;
+    sum += p;
+  }
+  sum = wave_sum(sum);
+  __builtin_amdgcn_wave_barrier();
+  // ---- o = sum_t p_t v_t
+  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int t0 = 0; t0 < a.T; t0 += 8) {
+    const int t = t0 + g;
+    if (t < a.T) {
+      float v[8];
+      load8(a.kv_hi, a.kv_lo, (row0 + t) * ld + vcol, v);
+      const float p = sc[wave][t];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = fmaf(p, v[j], o[j]);
+    }
+  }
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    o[j] += __shfl_xor(o[j], 8, 64);
+    o[j] += __shfl_xor(o[j], 16, 64);
+    o[j] += __shfl_xor(o[j], 32, 64);
+    o[j] *= inv;
+  }
+  if (g == 0) {
+    const int64_t off = (int64_t)seq * a.D + 64 * h + 8 * c;
+    bf16_t hi[8], lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (SPLIT) split_bf(o[j], hi[j], lo[j]);
+      else hi[j] = f2bf(o[j]);
+    }
+    *reinterpret_cast<uint4*>(a.out_hi + off) = make_uint4((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16),
+                                                           (uint32_t)hi[4] | ((uint32_t)hi[5] << 16), (uint32_t)hi[6] | ((uint32_t)hi[7] << 16));
+    if (SPLIT)
+      *reinterpret_cast<uint4*>(a.out_lo + off) = make_uint4((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16),
+                                                             (uint32_t)lo[4] | ((uint32_t)lo[5] << 16), (uint32_t)lo[6] | ((uint32_t)lo[7] << 16));
+  }
+}
+
 }  // namespace
+
+hipError_t launch_attention_pooled(const bf16_t* q_hi, const bf16_t* q_lo, const bf16_t* qkv_hi, const bf16_t* qkv_lo, bf16_t* out_hi,
+                                   bf16_t* out_lo, int32_t n_seq, int32_t T, int32_t H, int32_t D, bool split, hipStream_t s) {
+  if (T <= 0 || T > POOL_MAX_T || D != H * 64 || n_seq <= 0 || !q_hi || !qkv_hi || !out_hi) return hipErrorInvalidValue;
+  if (split && (!q_lo || !qkv_lo || !out_lo)) return hipErrorInvalidValue;
+  AttnPoolArgs a{q_hi, q_lo, qkv_hi, qkv_lo, out_hi, out_lo, n_seq, T, H, D};
+  const unsigned grid = (unsigned)((n_seq * H + 3) / 4);
+  if (split) hipLaunchKernelGGL(attn_pool_kernel<true>, dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(attn_pool_kernel<false>, dim3(grid), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
 
 hipError_t launch_attention(const AttnArgs& a, bool split, hipStream_t s) {
   if (a.T <= 0 || a.D != a.H * 64 || a.n_seq <= 0) return hipErrorInvalidValue;

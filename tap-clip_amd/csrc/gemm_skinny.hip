@@ -1,0 +1,163 @@
+// Skinny bf16 MFMA GEMM for gfx950:  C[M,N] = act(A[M,K] . W[N,K]^T + bias)  for a FEW HUNDRED rows (the CLS rows of the
+// image tower's last block: M = batch; tower.hip run_last_block_pooled) -- nn.Linear calls of open_clip's last
+// ResidualAttentionBlock restricted to the rows whose result the reference keeps (reference call site
+// models/clip_wrapper.py:46-47: `encode_image` returns the pooled CLS row).
+//
+// At M = 256 such a product is neither MFMA- nor bandwidth-bound (1.2 GFLOP, 4.7 MB of weights for the MLP GEMMs): it
+// is one workgroup's load-to-use latency, so the lever is the decomposition (guide, "Projection GEMM at M = 256"): the
+// 128 x 128-tile kernel of gemm.hip puts 12 - 48 workgroups on 256 CUs and walks K in 12 - 48 dependent steps (40 - 180 us
+// per GEMM, measured); here every workgroup takes all 256 rows x 64 columns of ONE K slice, (N / 64) x SPLITK ~ 150 - 256
+// workgroups, operands straight from global memory into MFMA fragments (no LDS: each operand byte is used once per
+// wave, the four waves of a workgroup re-read W through L1), fp32 partial slabs, and a finalize kernel that sums the
+// slabs in a fixed order (bitwise reproducible), adds the bias, applies the activation and rounds once.
+// bf16x3 (SPLIT): three products (A_hi W_hi + A_lo W_hi + A_hi W_lo) into the same accumulators, hi/lo outputs.
+#include "common.h"
+#include "kernels.h"
+
+namespace tapclip {
+namespace {
+
+struct SkinnyArgs {
+  const bf16_t *A_hi, *A_lo;  // [M, K], row stride lda
+  int64_t lda;
+  const bf16_t *W_hi, *W_lo;  // [N, K]
+  const float* bias;
+  int32_t M, N, K;
+  int32_t kslice;             // K steps of 32 per slice
+  float* slabs;               // [splitk][M_pad][N] fp32
+  int32_t m_pad;
+  bf16_t *out_hi, *out_lo;    // [M, N], row stride ldo
+  int64_t ldo;
+  int32_t act, epi, splitk;
+};
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.x * 64, part = blockIdx.y;
+  const int m_base = blockIdx.z * 256 + wave * 64;
+  if (m_base >= a.M) return;  // (wave-uniform; no barrier in this kernel)
+  const int k_begin = part * a.kslice * 32;
+  // lane (r, q): A fragment i = row m_base + 16 i + r, k = k0 + 8 q .. + 7; W fragment j = row n0 + 16 j + r, same k
+  int64_t a_row[4], w_row[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m_base + 16 * i + r;
+    if (m >= a.M) m = a.M - 1;  // clamp: rows past M are computed but never stored
+    a_row[i] = (int64_t)m * a.lda + k_begin + 8 * q;
+    w_row[i] = (int64_t)(n0 + 16 * i + r) * a.K + k_begin + 8 * q;
+  }
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  constexpr int NSEG = SPLIT ? 3 : 1;
+#pragma unroll
+  for (int seg = 0; seg < NSEG; ++seg) {
+    const bf16_t* Ab = (SPLIT && seg == 1) ? a.A_lo : a.A_hi;
+    const bf16_t* Wb = (SPLIT && seg == 2) ? a.W_lo : a.W_hi;
+#pragma unroll 2
+    for (int ks = 0; ks < a.kslice; ++ks) {
+      bf16x8_t af[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8_t*>(Ab + a_row[i] + ks * 32);
+        wf[i] = *reinterpret_cast<const bf16x8_t*>(Wb + w_row[i] + ks * 32);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j][i] = TAPCLIP_MFMA_16x16x32(wf[j], af[i], acc[j][i]);
+    }
+  }
+  // D = W . A^T: lane holds n = n0 + 16 j + 4 q + e (e = 0..3) of row m = m_base + 16 i + r
+  float* slab = a.slabs + ((size_t)part * a.m_pad) * a.N;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m_base + 16 * i + r;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4_t*>(slab + (size_t)m * a.N + n0 + 16 * j + 4 * q) = acc[j][i];
+  }
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void skinny_finalize_kernel(SkinnyArgs a) {
+  const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;  // float4 index over [M][N / 4]
+  const int n4 = a.N / 4;
+  if (i4 >= (int64_t)a.M * n4) return;
+  const int m = (int)(i4 / n4), n = (int)(i4 - (int64_t)m * n4) * 4;
+  f32x4_t v = a.bias ? *reinterpret_cast<const f32x4_t*>(a.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < a.splitk; ++p) v += *reinterpret_cast<const f32x4_t*>(a.slabs + ((size_t)p * a.m_pad + m) * a.N + n);
+  if (a.epi == EPI_BIAS_GELU_BF16) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = a.act == 0 ? (SPLIT ? gelu_erf(v[e]) : gelu_fast16(v[e])) : gelu_quick(v[e]);
+  }
+  bf16_t h[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (SPLIT) split_bf(v[e], h[e], l[e]);
+    else h[e] = f2bf(v[e]);
+  }
+  const int64_t o = (int64_t)m * a.ldo + n;
+  *reinterpret_cast<uint2*>(a.out_hi + o) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+  if (SPLIT) *reinterpret_cast<uint2*>(a.out_lo + o) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+}
+
+}  // namespace
+
+bool gemm_skinny_supports(const GemmArgs& g, int epilogue) {
+  return g.M >= 1 && g.M <= 1024 && g.N % 64 == 0 && g.K % 64 == 0 && g.lda % 8 == 0 && g.ldo % 4 == 0 &&
+         (epilogue == EPI_BIAS_BF16 || epilogue == EPI_BIAS_GELU_BF16) && g.out_hi != nullptr;
+}
+
+namespace {
+// K slices: enough workgroups for ~one per CU, slices of whole 64-deep steps, at most 16 slices
+int skinny_splitk(int64_t M, int32_t N, int32_t K) {
+  const int row_blocks = (int)((M + 255) / 256), col_blocks = N / 64, ksteps = K / 32;
+  int splitk = 256 / (row_blocks * col_blocks);
+  if (splitk < 1) splitk = 1;
+  if (splitk > 16) splitk = 16;
+  while (splitk > 1 && (ksteps % splitk != 0 || (ksteps / splitk) % 2 != 0)) --splitk;
+  return splitk;
+}
+}  // namespace
+
+// ws: >= gemm_skinny_ws_bytes(M, N, K) of fp32 scratch
+size_t gemm_skinny_ws_bytes(int64_t M, int32_t N, int32_t K) {
+  const int64_t m_pad = (M + 63) / 64 * 64;
+  return (size_t)skinny_splitk(M, N, K) * m_pad * N * sizeof(float);
+}
+
+hipError_t launch_gemm_skinny(const GemmArgs& g, int epilogue, bool split, float* ws, size_t ws_bytes, hipStream_t s) {
+  if (!gemm_skinny_supports(g, epilogue) || ws == nullptr) return hipErrorInvalidValue;
+  if (split && (!g.A_lo || !g.W_lo || !g.out_lo)) return hipErrorInvalidValue;
+  SkinnyArgs a;
+  a.A_hi = g.A_hi; a.A_lo = g.A_lo; a.lda = g.lda;
+  a.W_hi = g.W_hi; a.W_lo = g.W_lo;
+  a.bias = g.bias;
+  a.M = (int)g.M; a.N = g.N; a.K = g.K;
+  a.m_pad = (int)((g.M + 63) / 64 * 64);
+  a.out_hi = g.out_hi; a.out_lo = g.out_lo; a.ldo = g.ldo;
+  a.act = g.act; a.epi = epilogue;
+  const int row_blocks = (a.M + 255) / 256, col_blocks = a.N / 64;
+  const int splitk = skinny_splitk(a.M, a.N, a.K);
+  if (gemm_skinny_ws_bytes(a.M, a.N, a.K) > ws_bytes) return hipErrorInvalidValue;
+  a.splitk = splitk;
+  a.kslice = a.K / 32 / splitk;
+  a.slabs = ws;
+  const dim3 grid((unsigned)col_blocks, (unsigned)splitk, (unsigned)row_blocks);
+  const unsigned fin = (unsigned)(((int64_t)a.M * (a.N / 4) + 255) / 256);
+  if (split) {
+    hipLaunchKernelGGL(skinny_gemm_kernel<true>, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(skinny_finalize_kernel<true>, dim3(fin), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(skinny_gemm_kernel<false>, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(skinny_finalize_kernel<false>, dim3(fin), dim3(256), 0, s, a);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace tapclip

@@ -44,6 +44,11 @@ struct GemmArgs {
 size_t gemm256_split_ws_bytes();
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, bool split, hipStream_t s);
+// gemm_skinny.hip: a few hundred rows (M <= 1024), bf16 outputs (EPI_BIAS_BF16 / EPI_BIAS_GELU_BF16): (N / 64) x SPLITK
+// workgroups of all rows x 64 columns x one K slice, fp32 partial slabs in `ws`, summed in a fixed order by a finalize kernel
+bool gemm_skinny_supports(const GemmArgs& a, int epilogue);
+size_t gemm_skinny_ws_bytes(int64_t M, int32_t N, int32_t K);
+hipError_t launch_gemm_skinny(const GemmArgs& a, int epilogue, bool split, float* ws, size_t ws_bytes, hipStream_t s);
 
 // ---- MX-fp8 GEMM (gemm_mx8.hip): e4m3 elements, one e8m0 scale (2^(s-127)) per 32 consecutive k.
 // Scale arrays are k-step major: scale of (row, 32-block b) at [(b >> 1) * rows_pad + row] * 2 + (b & 1).
@@ -122,6 +127,10 @@ struct AttnArgs {
   unsigned long long* stamps = nullptr;  // diagnostic builds only (-DATTN_STAMP, tools/): [workgroup][8] s_memrealtime stamps
 };
 hipError_t launch_attention(const AttnArgs& a, bool split, hipStream_t s);
+// softmax(q K^T) V for ONE query row per sequence (the pooled token of a tower's last block): q [n_seq, D] (hi [+ lo]),
+// k / v taken from the q|k|v buffer [n_seq * T, 3 D] at columns D + 64 h / 2 D + 64 h, out [n_seq, D]
+hipError_t launch_attention_pooled(const bf16_t* q_hi, const bf16_t* q_lo, const bf16_t* qkv_hi, const bf16_t* qkv_lo, bf16_t* out_hi,
+                                   bf16_t* out_lo, int32_t n_seq, int32_t T, int32_t H, int32_t D, bool split, hipStream_t s);
 
 // probs [n,H,T,T] -> mean over H -> [n,T,T]
 hipError_t launch_head_mean(const float* probs, int32_t n, int32_t H, int32_t T, float* out, hipStream_t s);

@@ -80,6 +80,7 @@ struct tapclip_tower {
   bool split = false;
   bool fp8 = false;       // TAPCLIP_PREC_FP8: block GEMMs on MXFP8 (image tower only)
   bool x24 = false;       // image tower, bf16 / IEEE-half modes: the residual stream of the blocks in 24-bit planes (layernorm.hip XF = 2)
+  bool prune_last = true; // image tower: the last block computes K / V for every token but everything else for the CLS row only
   int tokens_vision = 0;  // G*G + 1
   int Kp = 0;             // padded 3*p*p
   std::vector<LayerW> layers;
@@ -432,8 +433,17 @@ int run_blocks_fp8(tapclip_tower* t, int64_t n_seq, int tokens, const Workspace&
 // capture_only: the caller wants the last block's attention capture (probs_last / attn_out_last), not the hidden states
 // -- pass 1 of FullModel.forward, reference models/model_wrapper.py:57-62 discards the transformer's output -- so the last
 // block stops after its attention core (literal capture: after its fp32 out_proj).
+// pooled_out != nullptr (image tower): only the CLS row of the last block's output is wanted -- open_clip pools token 0
+// before ln_post / proj, reference call site models/clip_wrapper.py:46-47 -- so the last block runs K / V for every
+// token and Q, the attention core, out_proj, LN2 and the MLP for the CLS rows only (run_last_block_pooled); the rest of
+// that block is dead work in the reference too, its results are discarded there.  On return pooled_out [n_seq, D] fp32
+// holds the CLS rows of the tower's output WITHOUT the last c_proj branch, which is pending in pooled_d (hi [+ lo]).
+int run_last_block_pooled(tapclip_tower* t, float* x, int64_t n_seq, int tokens, const Workspace& w, float* pooled_out, bf16_t** pooled_d_hi,
+                          bf16_t** pooled_d_lo, hipStream_t s);
+
 int run_blocks(tapclip_tower* t, float* x, int64_t n_seq, int tokens, int causal, const Workspace& w,
-               float* probs_last, float* attn_out_last, hipStream_t s, bool capture_only = false) {
+               float* probs_last, float* attn_out_last, hipStream_t s, bool capture_only = false, float* pooled_out = nullptr,
+               bf16_t** pooled_d_hi = nullptr, bf16_t** pooled_d_lo = nullptr) {
   const bool x24 = t->x24 && t->cfg.kind == TAPCLIP_TOWER_VISION;  // residual stream in w.x24_hi / w.x24_lo instead of x
   // image tower, 16-bit modes: the fp32 residual rows are streamed past the caches (layernorm.hip NTX)
   static const bool no_ntx = getenv("TAPCLIP_NO_STREAM_X") != nullptr;
@@ -454,6 +464,7 @@ int run_blocks(tapclip_tower* t, float* x, int64_t n_seq, int tokens, int causal
       else HIP_TRY(launch_add_layernorm_ex(3, x, w.a_hi, w.a_lo, w.d_hi, w.d_lo, L.ln1_g, L.ln1_b, M, D, w.xn_hi, w.xn_lo, s, stream_x));
       DBG_SYNC(1, s);
     }
+    if (last && pooled_out != nullptr) return run_last_block_pooled(t, x, n_seq, tokens, w, pooled_out, pooled_d_hi, pooled_d_lo, s);
     const int dbg_stop = dbg_stop_at();
     if (dbg_stop == 1 && li == 1) return TAPCLIP_OK;
     if (dbg_stop == 5 && li == 0) return TAPCLIP_OK;  // (3, 4, 5: block 0 after its first LayerNorm / LN2 / c_fc -- tools/dbg_ws2.py)
@@ -494,6 +505,60 @@ int run_blocks(tapclip_tower* t, float* x, int64_t n_seq, int tokens, int causal
     rc = gemm(t, 6, EPI_BIAS_BF16, w.h_hi, w.h_lo, F, L.wpr, L.bpr, M, D, F, w.d_hi, w.d_lo, nullptr, D, s);
     if (rc) return rc;
   }
+  return TAPCLIP_OK;
+}
+
+
+int run_last_block_pooled(tapclip_tower* t, float* x, int64_t n_seq, int tokens, const Workspace& w, float* pooled_out, bf16_t** pooled_d_hi,
+                          bf16_t** pooled_d_lo, hipStream_t s) {
+  // (LN1 of this block has run: x -- or its 24-bit planes -- holds every earlier branch, w.xn its normalised rows)
+  const LayerW& L = t->layers[t->cfg.layers - 1];
+  const int64_t M = n_seq * tokens;
+  const int D = t->cfg.width, F = t->cfg.mlp_dim, H = t->cfg.heads;
+  const bool x24 = t->x24;
+  int rc;
+  // buffers of the CLS-row tensors: fronts of workspace regions that are dead by the time they are written
+  bf16_t *q_hi = w.h_hi, *q_lo = w.h_lo;        // [n, D]   (h: free until the pooled c_fc)
+  bf16_t *ao_hi = w.ao_hi, *ao_lo = w.ao_lo;    // [n, D]
+  bf16_t *a_hi = w.a_hi, *a_lo = w.a_lo;        // [n, D]   (the previous block's branch was folded by LN1)
+  bf16_t *xn_hi = w.xn_hi, *xn_lo = w.xn_lo;    // [n, D]   (after the K / V and Q GEMMs have read every row)
+  bf16_t *h_hi = w.h_hi, *h_lo = w.h_lo;        // [n, F]   (after the attention core has read q)
+  bf16_t *d_hi = w.qkv_hi, *d_lo = w.qkv_lo;    // [n, D]   (after the attention core has read k, v)
+  // K and V of every token: rows D .. 3D - 1 of in_proj into columns D .. 3D - 1 of the q|k|v buffer
+  Packed wkv{L.wqkv.hi + (size_t)D * D, L.wqkv.lo ? L.wqkv.lo + (size_t)D * D : nullptr};
+  if ((rc = gemm(t, 2, EPI_BIAS_BF16, w.xn_hi, w.xn_lo, D, wkv, L.bqkv + D, M, 2 * D, D, w.qkv_hi + D, w.qkv_lo ? w.qkv_lo + D : nullptr,
+                 nullptr, 3 * D, s))) return rc;
+  ProfScope ps(t, 7, s);  // everything on the n_seq CLS rows is accounted to the pool / project slot
+  // Q of the CLS rows: A = row b * tokens of xn (row stride tokens * D)
+  GemmArgs g;
+  auto small_gemm = [&](int epi, const bf16_t* ah, const bf16_t* al, int64_t lda, const Packed& wt, const float* bias, int N, int K, bf16_t* oh,
+                        bf16_t* ol) {
+    GemmArgs a;
+    a.A_hi = ah; a.A_lo = al; a.lda = lda;
+    a.W_hi = wt.hi; a.W_lo = wt.lo;
+    a.bias = bias;
+    a.M = n_seq; a.N = N; a.K = K;
+    a.out_hi = oh; a.out_lo = ol; a.out_f32 = nullptr; a.ldo = N;
+    a.add_table = nullptr; a.rows_per_group = 0; a.act = t->cfg.act;
+    a.split_ws = t->split_ws;
+    // a few hundred rows: the split-K skinny kernel (gemm_skinny.hip); its fp32 slabs live in the handle's K-split
+    // scratch, which the tower's large GEMMs have allocated by now
+    if (t->split_ws != nullptr && gemm_skinny_supports(a, epi) && gemm_skinny_ws_bytes(n_seq, N, K) <= gemm256_split_ws_bytes())
+      return launch_gemm_skinny(a, epi, t->split, t->split_ws, gemm256_split_ws_bytes(), s);
+    return launch_gemm(a, epi, t->split, s);
+  };
+  (void)g;
+  HIP_TRY(small_gemm(EPI_BIAS_BF16, w.xn_hi, w.xn_lo, (int64_t)tokens * D, L.wqkv, L.bqkv, D, D, q_hi, q_lo));
+  HIP_TRY(launch_attention_pooled(q_hi, q_lo, w.qkv_hi, w.qkv_lo, ao_hi, ao_lo, (int)n_seq, tokens, H, D, t->split, s));
+  HIP_TRY(small_gemm(EPI_BIAS_BF16, ao_hi, ao_lo, D, L.wo, L.bo, D, D, a_hi, a_lo));
+  // the CLS rows of the residual stream -> fp32 [n, D], + out_proj's branch, LN2
+  if (x24) HIP_TRY(launch_gather_cls24(w.x24_hi, w.x24_lo, nullptr, (int)n_seq, tokens, D, pooled_out, s));
+  else HIP_TRY(hipMemcpy2DAsync(pooled_out, (size_t)D * 4, x, (size_t)tokens * D * 4, (size_t)D * 4, (size_t)n_seq, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(launch_add_layernorm(pooled_out, a_hi, a_lo, L.ln2_g, L.ln2_b, n_seq, D, xn_hi, xn_lo, s));
+  HIP_TRY(small_gemm(EPI_BIAS_GELU_BF16, xn_hi, xn_lo, D, L.wfc, L.bfc, F, D, h_hi, h_lo));
+  HIP_TRY(small_gemm(EPI_BIAS_BF16, h_hi, h_lo, F, L.wpr, L.bpr, D, F, d_hi, d_lo));
+  *pooled_d_hi = d_hi;
+  *pooled_d_lo = d_lo;
   return TAPCLIP_OK;
 }
 
@@ -651,6 +716,8 @@ int tapclip_tower_create(const tapclip_tower_cfg* cfg, tapclip_tower_t** out) {
     // MI355X gets wrong in lanes 48..63 beside another kernel's MFMAs: common.h TAPCLIP_TU_NO_PK_F32, DESIGN.md.)
     static const bool want_x24 = [] { const char* e = getenv("TAPCLIP_X24"); return e == nullptr || atoi(e) != 0; }();
     t->x24 = !t->split && !t->fp8 && layernorm_x24_supports(cfg->width) && want_x24;
+    static const bool no_prune = [] { const char* e = getenv("TAPCLIP_PRUNE_LAST"); return e && atoi(e) == 0; }();
+    t->prune_last = !no_prune;
     t->Kp = (3 * cfg->patch * cfg->patch + 63) / 64 * 64;
     for (const char* k : {"conv1.weight", "class_embedding", "positional_embedding", "ln_pre.weight", "ln_pre.bias",
                           "ln_post.weight", "ln_post.bias", "proj"})
@@ -820,6 +887,20 @@ int tapclip_encode_image(tapclip_tower_t* t, const float* images, int32_t B, flo
     // x24: ln_pre, the write of the 24-bit residual planes and block 0's ln_1 in one pass over the patch embeddings
     else if (t->x24) HIP_TRY(launch_layernorm_x24(0, 1, w.x, D, w.x24_hi, w.x24_lo, nullptr, nullptr, t->lnpre_g, t->lnpre_b, t->layers[0].ln1_g, t->layers[0].ln1_b, (int64_t)B * N, D, w.xn_hi, s));
     else HIP_TRY(launch_layernorm(w.x, D, t->lnpre_g, t->lnpre_b, (int64_t)B * N, D, nullptr, nullptr, w.x, s));
+  }
+  // CLS-only last block (not for the fp8 path, whose block GEMMs take MXFP8 operands; TAPCLIP_PRUNE_LAST=0 or
+  // tapclip_tower_set_flag(TAPCLIP_FLAG_PRUNE_LAST_BLOCK, 0) computes every row of every block)
+  const bool pooled = t->prune_last && !t->fp8 && t->cfg.layers >= 1;
+  if (pooled) {
+    // CLS rows of the output: fp32 [B, D].  With the 24-bit planes the fp32 buffer w.x is free; with an fp32 residual
+    // stream (w.x live) they go to the front of the pending-branch buffer w.d, which LN1 of the last block has consumed.
+    float* cls = t->x24 ? w.x : reinterpret_cast<float*>(w.d_hi);
+    bf16_t *pd_hi = nullptr, *pd_lo = nullptr;
+    rc = run_blocks(t, w.x, B, N, 0, w, nullptr, nullptr, s, false, cls, &pd_hi, &pd_lo);
+    if (rc) return rc;
+    ProfScope ps(t, 7, s);
+    HIP_TRY(launch_pool_project(cls, pd_hi, pd_lo, B, 1, D, nullptr, 0, t->lnpost_g, t->lnpost_b, t->proj, t->cfg.embed_dim, normalize, out, s));
+    return TAPCLIP_OK;
   }
   rc = t->fp8 ? run_blocks_fp8(t, B, N, w, s) : run_blocks(t, w.x, B, N, 0, w, nullptr, nullptr, s);
   if (rc) return rc;
@@ -1092,6 +1173,14 @@ int tapclip_mx8_gemm(const uint8_t* a_q, const uint8_t* a_scale, int64_t M, int6
   if (!gemm_mx8_supports(g)) return fail(TAPCLIP_EINVAL, "mx8 gemm needs N %% 256 == 0, K %% 64 == 0, K >= 256, m_pad %% 8 == 0 (M %lld N %d K %d m_pad %lld)", (long long)M, N, K, (long long)m_pad);
   HIP_TRY(launch_gemm_mx8(g, epi, static_cast<hipStream_t>(stream)));
   return TAPCLIP_OK;
+}
+
+int tapclip_tower_set_flag(tapclip_tower_t* t, int32_t flag, int32_t value) {
+  if (!t) return fail(TAPCLIP_EINVAL, "null tower");
+  switch (flag) {
+    case TAPCLIP_FLAG_PRUNE_LAST_BLOCK: t->prune_last = value != 0; return TAPCLIP_OK;
+    default: return fail(TAPCLIP_EINVAL, "unknown tower flag %d", flag);
+  }
 }
 
 int tapclip_profile_enable(tapclip_tower_t* t, int32_t on) {

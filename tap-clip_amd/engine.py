@@ -102,8 +102,16 @@ class _Tower:
 class VisionTower(_Tower):
     kind = _lib.TOWER_VISION
 
-    def __init__(self, cfg: ClipDims, state_dict, device="cuda", precision: str = "bf16"):
+    def __init__(self, cfg: ClipDims, state_dict, device="cuda", precision: str = "bf16", prune_last_block: Optional[bool] = None):
+        """prune_last_block: None keeps the library default (on, TAPCLIP_PRUNE_LAST=0 switches it off): the last block
+        computes K / V for every token and everything else for the CLS rows only -- `encode_image` returns nothing but
+        the pooled CLS row (include/tapclip.h TAPCLIP_FLAG_PRUNE_LAST_BLOCK).  False computes every row of every block."""
         super().__init__(cfg, cfg.vision, state_dict, device, precision)
+        if prune_last_block is not None:
+            self.set_prune_last_block(prune_last_block)
+
+    def set_prune_last_block(self, on: bool) -> None:
+        self._check(self.lib.tapclip_tower_set_flag(self.handle, _lib.FLAG_PRUNE_LAST_BLOCK, int(bool(on))))
 
     def _wanted(self, key):
         return key[len("visual."):] if key.startswith("visual.") else None

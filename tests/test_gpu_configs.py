@@ -465,6 +465,7 @@ def test_bench_spawns_its_ranks_at_the_configs3_shape(tmp_path):
         for i, c in enumerate(names):
             model.prompt_learner.context_bank[c].copy_(ctx[i])
         text_feat = model.text_features()
+        clip._vision.set_prune_last_block(False)  # the dumped logits are the headline's: every row of every block
         for rank in range(4):
             emb = clip._vision.encode_image(synth.make_images(256, cfg, seed=100 + rank).to(DEV), normalize=True)
             want = engine.logits(emb, text_feat, float(model.logit_scale.exp())).cpu()
@@ -490,12 +491,58 @@ def test_vit_l14_336_batch_128_properties(eng):
         assert torch.equal(a, b), f"{precision}: same input twice must be bit-identical"
         assert torch.allclose(a.norm(dim=-1), torch.ones(128, device=DEV), atol=1e-5)
         small = tower.encode_image(big[:2].clone(), normalize=True)
-        _report(f"ViT-L/14@336 batch 128 {precision}: golden rows in the big batch", a[:2], ref)
+        _report(f"ViT-L/14@336 batch 128 {precision}: golden rows in the big batch", a[:2].cpu(), ref)
         assert rel_l2(a[:2].cpu(), ref) < tol
         assert rel_l2(a[:2].cpu(), small.cpu()) < 1e-6, precision  # (first row tiles: no K-split tail involved)
         tower.close()
         del tower
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("name,batch", [("ViT-B-16", 64), ("ViT-B-32", 8), ("ViT-L-14-336", 3)])
+def test_pruned_last_block_equals_the_full_computation(eng, name, batch):
+    """The library default computes the image tower's LAST block for the CLS rows only (K and V for every token; Q, the
+    attention core, out_proj, LN2, the MLP for the pooled row: include/tapclip.h TAPCLIP_FLAG_PRUNE_LAST_BLOCK) -- the rows
+    the reference's pooling throws away (models/clip_wrapper.py:46-47).  Against the same tower computing every row of every
+    block, in every precision that has the path: equal to the precision's own rounding (the pooled row's softmax and P.V
+    run in fp32, the full kernel rounds P to 16 bits) -- bf16x3 to 1e-5, fp16 to 2e-4, bf16 to 1.5e-3 -- deterministic, and
+    independent of the batch the image sits in (ragged batch sizes included)."""
+    cfg = configs.get_config(name)
+    sd = synth.make_state_dict(cfg, seed=2, text=False)
+    images = synth.make_images(batch, cfg, 11).to(DEV)
+    for precision, tol in (("bf16x3", 1e-5), ("fp16", 2e-4), ("bf16", 1.5e-3)):
+        full = eng.VisionTower(cfg, sd, DEV, precision, prune_last_block=False)
+        pruned = eng.VisionTower(cfg, sd, DEV, precision)  # the default
+        a = full.encode_image(images, normalize=True)
+        b = pruned.encode_image(images, normalize=True)
+        _report(f"{name} {precision}: CLS-only last block vs full computation", b.cpu(), a.cpu())
+        assert rel_l2(b.cpu(), a.cpu()) < tol and rel_max(b.cpu(), a.cpu()) < 2 * tol
+        assert torch.equal(b, pruned.encode_image(images, normalize=True))
+        one = pruned.encode_image(images[:1].clone(), normalize=True)
+        assert torch.equal(one, b[:1]), "a pruned embedding must not depend on its batch mates"
+        pruned.set_prune_last_block(False)
+        assert torch.equal(pruned.encode_image(images, normalize=True), a), "the flag must switch the same handle back to the full computation"
+        for tw in (full, pruned):
+            tw.close()
+        del full, pruned
+        torch.cuda.empty_cache()
+
+
+def test_skinny_gemm_path_of_the_pooled_rows_vs_oracle(eng):
+    """The M = batch GEMMs of the pooled last block (gemm_skinny.hip: split-K slabs + finalize) end to end: a ONE-block
+    ViT-B/16-width tower, so the pooled path is the whole tower, at batch sizes that exercise one and several 256-row
+    blocks and ragged row counts, bf16x3 against the fp32 oracle at 1e-3."""
+    cfg = configs.ClipDims("blk1", 512, 224, 16, configs.TowerDims(768, 1, 12, 3072), configs.TowerDims(512, 1, 8, 2048), vocab=16, ctx=8)
+    ocfg = clip_ref.ClipDims("blk1", 512, 224, 16, clip_ref.TowerDims(768, 1, 12, 3072), clip_ref.TowerDims(512, 1, 8, 2048), vocab=16, ctx=8)
+    sd = synth.make_state_dict(cfg, seed=6, text=False)
+    tower = eng.VisionTower(cfg, sd, DEV, "bf16x3")
+    for batch in (1, 7, 300):
+        images = synth.make_images(batch, cfg, 20 + batch)
+        with torch.no_grad():
+            ref = clip_ref.encode_image(images[:8], sd, ocfg)
+        emb = tower.encode_image(images.to(DEV)).cpu()
+        assert rel_max(emb[:8], ref) < TOL, (batch, rel_max(emb[:8], ref))
+        assert bool(torch.isfinite(emb).all())
 
 
 def test_literal_replay_refuses_to_train():
