@@ -268,7 +268,9 @@ def main():
                                   f"{backend} all_gather through host memory -- REHEARSAL, {world} ranks on "
                                   f"{torch.cuda.device_count()} GPU(s): not a scaling measurement")},
         "logits_per_sec": round(value * args.classes, 1),
-        "encoder_mfma_frac": round(enc_flops * args.batch * world * args.steps / elapsed / (PEAK_BF16_TFLOPS * 1e12 * world), 4),
+        # against the dense peak of the headline precision's MFMA (bf16 / IEEE half: 2.5 PFLOP/s; fp8: the block-scaled 5 PFLOP/s)
+        "encoder_mfma_frac": round(enc_flops * args.batch * world * args.steps / elapsed /
+                                   ((PEAK_FP8_TFLOPS if args.precision == "fp8" else PEAK_BF16_TFLOPS) * 1e12 * world), 4),
         "encoder_gflop_per_image": round(enc_flops / 1e9, 3),
     }
     if elapsed_default is not None:

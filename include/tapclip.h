@@ -232,6 +232,20 @@ int tapclip_mx8_gemm(const uint8_t* a_q, const uint8_t* a_scale, int64_t M, int6
                      int32_t epilogue, int32_t act, float* out_f32, uint8_t* out_q, uint8_t* out_q_scale,
                      tapclip_stream_t stream);
 
+/* ---- the exchange step of the data-parallel path (BASELINE.json north_star: "an RCCL all-gather over xGMI of the image
+ * embeddings before the logit-scale cosine-similarity matrix"; nothing of it exists in the single-process reference,
+ * /root/reference/train.py:30) for hosts WITHOUT torch.distributed.  One process per GPU; rank 0 draws an id and hands
+ * its TAPCLIP_COMM_ID_BYTES bytes to the other ranks out of band; every rank then calls tapclip_comm_create (collective,
+ * on the HIP device it will use) and tapclip_allgather(send [bytes_per_rank] -> recv [world * bytes_per_rank], rank-major)
+ * on its stream.  A thin layer over RCCL, which is opened at the first call (no link-time dependency).  The Python side
+ * of this repository uses torch.distributed for the same step (tap-clip_amd/dist.py). */
+typedef struct tapclip_comm tapclip_comm_t;
+#define TAPCLIP_COMM_ID_BYTES 128
+int tapclip_comm_unique_id(void* id_out);
+int tapclip_comm_create(const void* id, int32_t rank, int32_t world, tapclip_comm_t** out);
+int tapclip_allgather(tapclip_comm_t* comm, const void* send, void* recv, size_t bytes_per_rank, tapclip_stream_t stream);
+void tapclip_comm_destroy(tapclip_comm_t* comm);
+
 /* ---- behaviour switches of a tower handle.
  * TAPCLIP_FLAG_PRUNE_LAST_BLOCK (image towers, default 1; not the fp8 precision): `encode_image` returns the CLS row only
  * (open_clip pools token 0 before ln_post / proj; reference call site models/clip_wrapper.py:46-47), so in the LAST block

@@ -49,6 +49,10 @@ SYMBOLS = [
     ("tapclip_gemm_f32", _i32, [_p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _sz, _p]),
     ("tapclip_mx8_quantize", _i32, [_p, _i64, _i32, _p, _p, _i64, _p]),
     ("tapclip_mx8_gemm", _i32, [_p, _p, _i64, _i64, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
+    ("tapclip_comm_unique_id", _i32, [_p]),
+    ("tapclip_comm_create", _i32, [_p, _i32, _i32, C.POINTER(_p)]),
+    ("tapclip_allgather", _i32, [_p, _p, _p, _sz, _p]),
+    ("tapclip_comm_destroy", None, [_p]),
     ("tapclip_tower_set_flag", _i32, [_p, _i32, _i32]),
     ("tapclip_profile_enable", _i32, [_p, _i32]),
     ("tapclip_profile_read", _i32, [_p, C.POINTER(_f32), C.POINTER(_i64)]),

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <new>
 #include <set>
 #include <string>
 #include <vector>
@@ -1173,6 +1174,94 @@ int tapclip_mx8_gemm(const uint8_t* a_q, const uint8_t* a_scale, int64_t M, int6
   if (!gemm_mx8_supports(g)) return fail(TAPCLIP_EINVAL, "mx8 gemm needs N %% 256 == 0, K %% 64 == 0, K >= 256, m_pad %% 8 == 0 (M %lld N %d K %d m_pad %lld)", (long long)M, N, K, (long long)m_pad);
   HIP_TRY(launch_gemm_mx8(g, epi, static_cast<hipStream_t>(stream)));
   return TAPCLIP_OK;
+}
+
+
+// ---- the one exchange step of the data-parallel path for hosts WITHOUT torch.distributed (SURVEY.md section 8b lists
+// tapclip_allgather among the exports; the Python side keeps torch.distributed, tap-clip_amd/dist.py): a thin layer over
+// RCCL.  librccl is opened at the first call (dlopen by its soname: inside a PyTorch process that is the copy
+// torch already loaded), so the library itself carries no link-time dependency on it.
+namespace {
+struct Id128 {  // ncclUniqueId: 128 opaque bytes, passed BY VALUE to ncclCommInitRank
+  char b[128];
+};
+struct RcclApi {
+  void* handle = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi& rccl() {
+  static RcclApi api = [] {
+    RcclApi a;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (a.handle) break;
+    }
+    if (a.handle) {
+      a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(a.handle, "ncclGetUniqueId"));
+      a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(a.handle, "ncclCommInitRank"));
+      a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(a.handle, "ncclAllGather"));
+      a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.handle, "ncclCommDestroy"));
+      a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.handle, "ncclGetErrorString"));
+      if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.CommDestroy) a.handle = nullptr;
+    }
+    return a;
+  }();
+  return api;
+}
+int rccl_fail(const char* what, int rc) {
+  const RcclApi& a = rccl();
+  return fail(TAPCLIP_EHIP, "%s failed: %s", what, a.GetErrorString ? a.GetErrorString(rc) : "RCCL error");
+}
+}  // namespace
+
+struct tapclip_comm {
+  void* nccl = nullptr;
+  int rank = 0, world = 1;
+};
+
+int tapclip_comm_unique_id(void* id_out) {
+  if (!id_out) return fail(TAPCLIP_EINVAL, "null argument");
+  RcclApi& a = rccl();
+  if (!a.handle) return fail(TAPCLIP_ESTATE, "librccl not found (dlopen of librccl.so.1 failed)");
+  const int rc = a.GetUniqueId(id_out);
+  return rc ? rccl_fail("ncclGetUniqueId", rc) : TAPCLIP_OK;
+}
+
+int tapclip_comm_create(const void* id, int32_t rank, int32_t world, tapclip_comm_t** out) {
+  if (!id || !out) return fail(TAPCLIP_EINVAL, "null argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(TAPCLIP_EINVAL, "bad rank / world (%d, %d)", rank, world);
+  RcclApi& a = rccl();
+  if (!a.handle) return fail(TAPCLIP_ESTATE, "librccl not found (dlopen of librccl.so.1 failed)");
+  Id128 uid;
+  memcpy(uid.b, id, sizeof(uid.b));
+  tapclip_comm* c = new (std::nothrow) tapclip_comm;
+  if (!c) return fail(TAPCLIP_ENOMEM, "out of host memory");
+  c->rank = rank;
+  c->world = world;
+  const int rc = a.CommInitRank(&c->nccl, world, uid, rank);  // collective over the `world` ranks (current HIP device)
+  if (rc) {
+    delete c;
+    return rccl_fail("ncclCommInitRank", rc);
+  }
+  *out = c;
+  return TAPCLIP_OK;
+}
+
+int tapclip_allgather(tapclip_comm_t* comm, const void* send, void* recv, size_t bytes_per_rank, tapclip_stream_t stream) {
+  if (!comm || !send || !recv) return fail(TAPCLIP_EINVAL, "null argument");
+  if (bytes_per_rank == 0) return TAPCLIP_OK;
+  const int rc = rccl().AllGather(send, recv, bytes_per_rank, /* ncclChar */ 0, comm->nccl, static_cast<hipStream_t>(stream));
+  return rc ? rccl_fail("ncclAllGather", rc) : TAPCLIP_OK;
+}
+
+void tapclip_comm_destroy(tapclip_comm_t* comm) {
+  if (!comm) return;
+  if (comm->nccl) (void)rccl().CommDestroy(comm->nccl);
+  delete comm;
 }
 
 int tapclip_tower_set_flag(tapclip_tower_t* t, int32_t flag, int32_t value) {

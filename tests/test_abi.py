@@ -117,6 +117,9 @@ for h, kind in handles:
     rc = lib.tapclip_text_forward(h, dummy, 4, 8, 0, dummy, None, None, None, dummy, 64, None)
     assert rc in (_lib.EINVAL, _lib.ESTATE), rc
     assert lib.tapclip_profile_enable(h, 1) == 0 and lib.tapclip_profile_enable(None, 1) == _lib.EINVAL
+    assert lib.tapclip_tower_set_flag(h, _lib.FLAG_PRUNE_LAST_BLOCK, 0) == 0 and lib.tapclip_tower_set_flag(h, _lib.FLAG_PRUNE_LAST_BLOCK, 1) == 0
+    assert lib.tapclip_tower_set_flag(h, 99, 1) == _lib.EINVAL and "unknown tower flag" in err()
+    assert lib.tapclip_tower_set_flag(None, _lib.FLAG_PRUNE_LAST_BLOCK, 1) == _lib.EINVAL
     ms, n = (C.c_float * len(_lib.PROFILE_SLOTS))(), (C.c_int64 * len(_lib.PROFILE_SLOTS))()
     assert lib.tapclip_profile_read(h, ms, n) == 0 and sum(n) == 0
 for h, _ in handles:
@@ -137,6 +140,14 @@ assert lib.tapclip_mx8_gemm(dummy, dummy, 8, 8, dummy, dummy, None, 256, 256, 0,
 ms6 = (C.c_float * 6)(0.5, 0.5, 0.5, 0.0, 0.2, 0.2)
 assert lib.tapclip_preprocess_u8(dummy, dummy, 2, 224, ms6, dummy, dummy, None) == _lib.EINVAL and "std" in err()
 assert lib.tapclip_preprocess_u8(dummy, dummy, 0, 224, ms6, dummy, dummy, None) == _lib.EINVAL
+# ---- communicator: argument validation (no RCCL call is reached)
+idbuf = (C.c_char * 128)()
+comm = C.c_void_p()
+assert lib.tapclip_comm_unique_id(None) == _lib.EINVAL
+assert lib.tapclip_comm_create(None, 0, 1, C.byref(comm)) == _lib.EINVAL
+assert lib.tapclip_comm_create(idbuf, 2, 2, C.byref(comm)) == _lib.EINVAL and "bad rank" in err()
+assert lib.tapclip_allgather(None, dummy, dummy, 64, None) == _lib.EINVAL
+lib.tapclip_comm_destroy(None)
 assert lib.tapclip_abi_version() == 1
 print("sanitized host paths ok")
 """

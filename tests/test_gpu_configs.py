@@ -545,6 +545,36 @@ def test_skinny_gemm_path_of_the_pooled_rows_vs_oracle(eng):
         assert bool(torch.isfinite(emb).all())
 
 
+def test_c_abi_allgather_over_rccl_one_rank():
+    """tapclip_comm_* / tapclip_allgather (include/tapclip.h: the exchange step for hosts without torch.distributed) on a
+    communicator of ONE rank -- all a 1-GPU box can host: unique id, ncclCommInitRank, a 512-KiB all-gather of the size
+    configs[3] moves per rank on the caller's stream, destroy.  In a child process, so that the library's own dlopen of
+    librccl is what runs (not a copy a torch process group already initialised)."""
+    code = r"""
+import ctypes as C, sys, torch
+sys.path.insert(0, %r)
+import tap_clip_amd
+from tap_clip_amd import _lib
+lib = _lib.load()
+torch.cuda.set_device(0)
+idbuf = (C.c_char * 128)()
+_lib.check(lib.tapclip_comm_unique_id(idbuf))
+comm = C.c_void_p()
+_lib.check(lib.tapclip_comm_create(idbuf, 0, 1, C.byref(comm)))
+x = torch.nn.functional.normalize(torch.randn(256, 512, device="cuda"), dim=-1)
+y = torch.zeros_like(x)
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+_lib.check(lib.tapclip_allgather(comm, x.data_ptr(), y.data_ptr(), x.numel() * 4, st))
+torch.cuda.synchronize()
+assert torch.equal(x, y)
+lib.tapclip_comm_destroy(comm)
+print("abi allgather ok")
+""" % ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "abi allgather ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_literal_replay_refuses_to_train():
     g = golden("fullmodel_intended_tiny")
     model, images = _build_full("tiny", g, "intended", "bf16", collapse=False)
