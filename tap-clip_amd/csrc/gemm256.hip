@@ -596,14 +596,15 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
   }
   const int64_t tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
   // persistent: one workgroup per CU (a multiple of 8 so every XCD gets the same number)
-  static int n_cu = 0;
-  if (n_cu == 0) {
+  static int n_cu_dev = 0;
+  if (n_cu_dev == 0) {
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-    n_cu = prop.multiProcessorCount / 8 * 8;
-    if (n_cu < 8) n_cu = 8;
+    n_cu_dev = prop.multiProcessorCount / 8 * 8;
+    if (n_cu_dev < 8) n_cu_dev = 8;
   }
+  const int n_cu = (a.n_cu >= 8 && a.n_cu < n_cu_dev) ? a.n_cu / 8 * 8 : n_cu_dev;  // (a CU-masked stream: one workgroup per CU of the mask)
   int64_t nwg = tiles < n_cu ? (tiles + 7) / 8 * 8 : n_cu;
   GemmArgs b = a;
   static const int gm_env = [] {

@@ -40,6 +40,7 @@ struct GemmArgs {
   // of K as raw fp32 partial tiles [256][BN] in split_ws; a fix-up kernel sums them and applies the epilogue
   float* split_ws = nullptr;       // caller-provided scratch, >= gemm256_split_ws_bytes()
   int32_t split_from = 0, split_parts = 0;  // filled by the launcher
+  int32_t n_cu = 0;  // gemm256.hip: size the persistent grid for this many CUs (0 = the whole device); for launches on a CU-masked stream
 };
 size_t gemm256_split_ws_bytes();
 
