@@ -575,6 +575,10 @@ __global__ __launch_bounds__(256) void splitk_fixup_kernel(GemmArgs g, int n_til
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = g.act == 0 ? gelu_fast16(v[e]) : gelu_quick(v[e]);
   }
+  if (EPI == EPI_BIAS_F32) {  // (the dX GEMMs of the prompt-tuning backward: fp32 gradients)
+    *reinterpret_cast<f32x4_t*>(g.out_f32 + m * g.ldo + n) = v;
+    return;
+  }
   uint2 ph;
   ph.x = pack_bf2(v[0], v[1]);
   ph.y = pack_bf2(v[2], v[3]);
@@ -619,7 +623,9 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
   static const bool no_tail_split = getenv("TAPCLIP_NO_TAIL_SPLIT") != nullptr;
   // The same machinery covers a GEMM with fewer tiles than half the CUs (the text tower's c_proj: 96 tiles of
   // K = 2048 on 256 CUs, 40 us): every tile is K-split (split_from = 0) and the grid grows to tiles x parts.
-  if (!SPLIT && (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16) && a.split_ws != nullptr && !no_tail_split) {
+  // (EPI_BIAS_F32: the K = 1536 / 2048, N = 512 dX GEMMs of the text tower's backward -- one partial round of 48 - 96 tiles
+  // and 48 - 64 dependent k-steps, 37.5 us; K-split two ways + the fix-up: see DESIGN.md section 6)
+  if (!SPLIT && (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_BIAS_F32) && a.split_ws != nullptr && !no_tail_split) {
     const int64_t full = tiles / n_cu, rem = tiles - full * n_cu;
     const int ks = a.K / BKS;
     if (rem > 0 && rem * 2 <= n_cu && (full == 0 || BN == 256)) {
@@ -640,7 +646,7 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((gemm256_kernel<EPI, SPLIT, BN, NS>), dim3((unsigned)nwg), dim3(512), smem_bytes, s, b);
   if (b.split_parts > 0) {
     const int n_tail = (int)(tiles - b.split_from);
-    if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16)
+    if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_BIAS_F32)
       hipLaunchKernelGGL((splitk_fixup_kernel<EPI, BN>), dim3((unsigned)(n_tail * (BM * BN / 4 / 256))), dim3(256), 0, s, b, n_tail);
   }
   return hipGetLastError();
@@ -662,9 +668,9 @@ hipError_t launch_e(const GemmArgs& a, bool split, hipStream_t s) {
     const double t256 = std::ceil(r256) * 1.0, t128 = std::ceil(r128) * 0.5 * 1.25;  // relative time per round
     wide = forced_bn == 256 || (forced_bn != 128 && t256 <= t128);
   }
-  // (the GELU-backward epilogue spills 84 B/lane at 256-wide tiles: its exp + erf polynomial beside 128
-  // accumulator registers; the 128-wide instantiation does not)
-  if (EPI == EPI_GELU_BWD_BF16 && forced_bn != 256) wide = false;
+  // (the GELU-backward epilogue used to be pinned to 128-wide tiles: at 256 it spilled 84 B/lane -- its exp + erf polynomial
+  // beside 128 accumulator registers.  Since the epilogue moved out of the k-loop (round 3) the 256-wide instantiation
+  // allocates 249 VGPRs without scratch, and the text tower's N = 2048 recompute GEMM runs one round of 192 tiles.)
   if (wide) return split ? launch_t<EPI, true, 256>(a, s) : launch_t<EPI, false, 256>(a, s);
   return split ? launch_t<EPI, true, 128>(a, s) : launch_t<EPI, false, 128>(a, s);
 }
