@@ -109,15 +109,18 @@ __global__ __launch_bounds__(256) void skinny_finalize_kernel(SkinnyArgs a) {
 }  // namespace
 
 bool gemm_skinny_supports(const GemmArgs& g, int epilogue) {
-  return g.M >= 1 && g.M <= 1024 && g.N % 64 == 0 && g.K % 64 == 0 && g.lda % 8 == 0 && g.ldo % 4 == 0 &&
+  return g.M >= 1 && g.N % 64 == 0 && g.K % 64 == 0 && g.lda % 8 == 0 && g.ldo % 4 == 0 &&
          (epilogue == EPI_BIAS_BF16 || epilogue == EPI_BIAS_GELU_BF16) && g.out_hi != nullptr;
 }
 
 namespace {
-// K slices: enough workgroups for ~one per CU, slices of whole 64-deep steps, at most 16 slices
-int skinny_splitk(int64_t M, int32_t N, int32_t K) {
-  const int row_blocks = (int)((M + 255) / 256), col_blocks = N / 64, ksteps = K / 32;
-  int splitk = 256 / (row_blocks * col_blocks);
+constexpr int64_t CHUNK_ROWS = 1024;  // rows per launch pair (the slabs of one chunk are re-used by the next)
+// K slices: enough workgroups for ~one per CU at up to 256 rows, slices of whole 64-deep steps, at most 16 slices.
+// A function of (N, K) ONLY: the slices fix the order of the fp32 sums, so a row's result does not depend on how many
+// other rows the call carries (bitwise batch invariance of the pooled embeddings).
+int skinny_splitk(int32_t N, int32_t K) {
+  const int col_blocks = N / 64, ksteps = K / 32;
+  int splitk = 256 / col_blocks;
   if (splitk < 1) splitk = 1;
   if (splitk > 16) splitk = 16;
   while (splitk > 1 && (ksteps % splitk != 0 || (ksteps / splitk) % 2 != 0)) --splitk;
@@ -125,37 +128,40 @@ int skinny_splitk(int64_t M, int32_t N, int32_t K) {
 }
 }  // namespace
 
-// ws: >= gemm_skinny_ws_bytes(M, N, K) of fp32 scratch
+// ws: >= gemm_skinny_ws_bytes(M, N, K) of fp32 scratch (rows beyond CHUNK_ROWS go through the same slabs, chunk by chunk)
 size_t gemm_skinny_ws_bytes(int64_t M, int32_t N, int32_t K) {
-  const int64_t m_pad = (M + 63) / 64 * 64;
-  return (size_t)skinny_splitk(M, N, K) * m_pad * N * sizeof(float);
+  const int64_t rows = M < CHUNK_ROWS ? M : CHUNK_ROWS;
+  const int64_t m_pad = (rows + 63) / 64 * 64;
+  return (size_t)skinny_splitk(N, K) * m_pad * N * sizeof(float);
 }
 
 hipError_t launch_gemm_skinny(const GemmArgs& g, int epilogue, bool split, float* ws, size_t ws_bytes, hipStream_t s) {
   if (!gemm_skinny_supports(g, epilogue) || ws == nullptr) return hipErrorInvalidValue;
   if (split && (!g.A_lo || !g.W_lo || !g.out_lo)) return hipErrorInvalidValue;
-  SkinnyArgs a;
-  a.A_hi = g.A_hi; a.A_lo = g.A_lo; a.lda = g.lda;
-  a.W_hi = g.W_hi; a.W_lo = g.W_lo;
-  a.bias = g.bias;
-  a.M = (int)g.M; a.N = g.N; a.K = g.K;
-  a.m_pad = (int)((g.M + 63) / 64 * 64);
-  a.out_hi = g.out_hi; a.out_lo = g.out_lo; a.ldo = g.ldo;
-  a.act = g.act; a.epi = epilogue;
-  const int row_blocks = (a.M + 255) / 256, col_blocks = a.N / 64;
-  const int splitk = skinny_splitk(a.M, a.N, a.K);
-  if (gemm_skinny_ws_bytes(a.M, a.N, a.K) > ws_bytes) return hipErrorInvalidValue;
-  a.splitk = splitk;
-  a.kslice = a.K / 32 / splitk;
-  a.slabs = ws;
-  const dim3 grid((unsigned)col_blocks, (unsigned)splitk, (unsigned)row_blocks);
-  const unsigned fin = (unsigned)(((int64_t)a.M * (a.N / 4) + 255) / 256);
-  if (split) {
-    hipLaunchKernelGGL(skinny_gemm_kernel<true>, grid, dim3(256), 0, s, a);
-    hipLaunchKernelGGL(skinny_finalize_kernel<true>, dim3(fin), dim3(256), 0, s, a);
-  } else {
-    hipLaunchKernelGGL(skinny_gemm_kernel<false>, grid, dim3(256), 0, s, a);
-    hipLaunchKernelGGL(skinny_finalize_kernel<false>, dim3(fin), dim3(256), 0, s, a);
+  if (gemm_skinny_ws_bytes(g.M, g.N, g.K) > ws_bytes) return hipErrorInvalidValue;
+  const int splitk = skinny_splitk(g.N, g.K);
+  for (int64_t r0 = 0; r0 < g.M; r0 += CHUNK_ROWS) {
+    SkinnyArgs a;
+    const int64_t rows = g.M - r0 < CHUNK_ROWS ? g.M - r0 : CHUNK_ROWS;
+    a.A_hi = g.A_hi + r0 * g.lda; a.A_lo = g.A_lo ? g.A_lo + r0 * g.lda : nullptr; a.lda = g.lda;
+    a.W_hi = g.W_hi; a.W_lo = g.W_lo;
+    a.bias = g.bias;
+    a.M = (int)rows; a.N = g.N; a.K = g.K;
+    a.m_pad = (int)((rows + 63) / 64 * 64);
+    a.out_hi = g.out_hi + r0 * g.ldo; a.out_lo = g.out_lo ? g.out_lo + r0 * g.ldo : nullptr; a.ldo = g.ldo;
+    a.act = g.act; a.epi = epilogue;
+    a.splitk = splitk;
+    a.kslice = a.K / 32 / splitk;
+    a.slabs = ws;
+    const dim3 grid((unsigned)(a.N / 64), (unsigned)splitk, (unsigned)((a.M + 255) / 256));
+    const unsigned fin = (unsigned)(((int64_t)a.M * (a.N / 4) + 255) / 256);
+    if (split) {
+      hipLaunchKernelGGL(skinny_gemm_kernel<true>, grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL(skinny_finalize_kernel<true>, dim3(fin), dim3(256), 0, s, a);
+    } else {
+      hipLaunchKernelGGL(skinny_gemm_kernel<false>, grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL(skinny_finalize_kernel<false>, dim3(fin), dim3(256), 0, s, a);
+    }
   }
   return hipGetLastError();
 }

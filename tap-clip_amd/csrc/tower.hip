@@ -542,10 +542,18 @@ int run_last_block_pooled(tapclip_tower* t, float* x, int64_t n_seq, int tokens,
     a.out_hi = oh; a.out_lo = ol; a.out_f32 = nullptr; a.ldo = N;
     a.add_table = nullptr; a.rows_per_group = 0; a.act = t->cfg.act;
     a.split_ws = t->split_ws;
-    // a few hundred rows: the split-K skinny kernel (gemm_skinny.hip); its fp32 slabs live in the handle's K-split
-    // scratch, which the tower's large GEMMs have allocated by now
-    if (t->split_ws != nullptr && gemm_skinny_supports(a, epi) && gemm_skinny_ws_bytes(n_seq, N, K) <= gemm256_split_ws_bytes())
+    // a few hundred rows: the split-K skinny kernel (gemm_skinny.hip), for EVERY batch size -- its K slices depend on (N, K)
+    // only, so a pooled row sums in the same order whatever its batch (bitwise batch invariance).  Its fp32 slabs live in
+    // the handle's K-split scratch (allocated here when no large GEMM has done it yet: small batches).
+    if (gemm_skinny_supports(a, epi) && gemm_skinny_ws_bytes(n_seq, N, K) <= gemm256_split_ws_bytes()) {
+      if (t->split_ws == nullptr) {
+        void* p = nullptr;
+        if (dev_alloc(t, gemm256_split_ws_bytes(), &p) != TAPCLIP_OK) return hipErrorOutOfMemory;
+        t->split_ws = static_cast<float*>(p);
+        a.split_ws = t->split_ws;
+      }
       return launch_gemm_skinny(a, epi, t->split, t->split_ws, gemm256_split_ws_bytes(), s);
+    }
     return launch_gemm(a, epi, t->split, s);
   };
   (void)g;

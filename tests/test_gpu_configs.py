@@ -499,14 +499,15 @@ def test_vit_l14_336_batch_128_properties(eng):
         torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("name,batch", [("ViT-B-16", 64), ("ViT-B-32", 8), ("ViT-L-14-336", 3)])
+@pytest.mark.parametrize("name,batch", [("ViT-B-16", 64), ("ViT-B-32", 8), ("ViT-L-14-336", 3), ("tiny", 1100)])
 def test_pruned_last_block_equals_the_full_computation(eng, name, batch):
     """The library default computes the image tower's LAST block for the CLS rows only (K and V for every token; Q, the
     attention core, out_proj, LN2, the MLP for the pooled row: include/tapclip.h TAPCLIP_FLAG_PRUNE_LAST_BLOCK) -- the rows
     the reference's pooling throws away (models/clip_wrapper.py:46-47).  Against the same tower computing every row of every
     block, in every precision that has the path: equal to the precision's own rounding (the pooled row's softmax and P.V
     run in fp32, the full kernel rounds P to 16 bits) -- bf16x3 to 1e-5, fp16 to 2e-4, bf16 to 1.5e-3 -- deterministic, and
-    independent of the batch the image sits in (ragged batch sizes included)."""
+    independent of the batch the image sits in (ragged batch sizes included).  ("tiny" at batch 1100: more rows than the
+    skinny GEMM takes, so the pooled rows fall back to the tiled kernel; width 128, so the residual stream is fp32.)"""
     cfg = configs.get_config(name)
     sd = synth.make_state_dict(cfg, seed=2, text=False)
     images = synth.make_images(batch, cfg, 11).to(DEV)
