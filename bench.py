@@ -185,7 +185,7 @@ def main():
     # The headline times the FULL computation -- every row of every block, the 35.127 GFLOP per image of SURVEY.md
     # section 8d -- so the library's default CLS-only last block (include/tapclip.h TAPCLIP_FLAG_PRUNE_LAST_BLOCK: same
     # embeddings, 7 % fewer FLOPs) is switched off here and reported separately below as `default_path`.
-    pruning = args.precision != "fp8"  # (the fp8 path has no pruned last block)
+    pruning = True
     if pruning:
         vision.set_prune_last_block(False)
     scale = float(model.logit_scale.detach().exp())
@@ -282,7 +282,8 @@ def main():
                     "the headline `value` above does NOT use it (it times every row of every block)",
             "img_per_s": round(total_images / elapsed_default, 1), "ms_per_step": round(1e3 * elapsed_default / args.steps, 4),
             "executed_gflop_per_image": round(ex / 1e9, 3),
-            "encoder_mfma_frac_executed": round(ex * total_images / elapsed_default / (PEAK_BF16_TFLOPS * 1e12 * world), 4),
+            "encoder_mfma_frac_executed": round(ex * total_images / elapsed_default /
+                                                ((PEAK_FP8_TFLOPS if args.precision == "fp8" else PEAK_BF16_TFLOPS) * 1e12 * world), 4),
         }
 
     def kernel_table(prof_, steps_):
@@ -548,8 +549,7 @@ def main():
                 own = prec == args.precision
                 cw = clip if own else CLIPWrapper(args.model, None, str(dev), precision=prec, attn_semantics="intended", state_dict=sd)
                 tw = cw._vision
-                if prec != "fp8":
-                    tw.set_prune_last_block(False)  # img_per_s / kernels: the full computation, like the headline
+                tw.set_prune_last_block(False)  # img_per_s / kernels: the full computation, like the headline
                 its = n_it if prec != "bf16x3" else 3
                 for _ in range(2):
                     e = tw.encode_image(images, normalize=True)
@@ -581,16 +581,15 @@ def main():
                         row["gemm_family"] = {"achieved": round(g_fl_p / (g_ms_p * 1e-3) / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                               "frac": round(g_fl_p / (g_ms_p * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                                               "avg_launch_us": round(1e3 * g_ms_p / g_n_p, 2)}
-                if prec != "fp8":
-                    tw.set_prune_last_block(True)  # the shipped default: its speed, and the errors below are ITS errors
-                    for _ in range(2):
-                        tw.encode_image(images, normalize=True)
-                    torch.cuda.synchronize(dev)
-                    t1 = time.perf_counter()
-                    for _ in range(its):
-                        engine.logits(tw.encode_image(images, normalize=True), text_feat, scale)
-                    torch.cuda.synchronize(dev)
-                    row["img_per_s_default_path"] = round(args.batch * its / (time.perf_counter() - t1), 1)
+                tw.set_prune_last_block(True)  # the shipped default: its speed, and the errors below are ITS errors
+                for _ in range(2):
+                    tw.encode_image(images, normalize=True)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(its):
+                    engine.logits(tw.encode_image(images, normalize=True), text_feat, scale)
+                torch.cuda.synchronize(dev)
+                row["img_per_s_default_path"] = round(args.batch * its / (time.perf_counter() - t1), 1)
                 if oracle_logits is not None:
                     with contextlib.redirect_stdout(sys.stderr):
                         fm = FullModel(names, cw, prompt_len=args.prompt_len, class_specific=True).eval()

@@ -247,11 +247,12 @@ int tapclip_allgather(tapclip_comm_t* comm, const void* send, void* recv, size_t
 void tapclip_comm_destroy(tapclip_comm_t* comm);
 
 /* ---- behaviour switches of a tower handle.
- * TAPCLIP_FLAG_PRUNE_LAST_BLOCK (image towers, default 1; not the fp8 precision): `encode_image` returns the CLS row only
+ * TAPCLIP_FLAG_PRUNE_LAST_BLOCK (image towers, default 1): `encode_image` returns the CLS row only
  * (open_clip pools token 0 before ln_post / proj; reference call site models/clip_wrapper.py:46-47), so in the LAST block
  * every other row's query, attention output, out_proj and MLP are dead work -- the reference computes them and throws
  * them away.  With the flag on, the last block computes K and V for every token and the rest for the CLS rows only
- * (same results to rounding: the CLS row's softmax and P.V run in fp32 there).  0 = compute every row of every block
+ * (same results to rounding: the CLS row's softmax and P.V run in fp32 there; in the fp8 precision the pooled rows' last block
+ * runs on 16-bit copies of that block's weights).  0 = compute every row of every block
  * (what bench.py's headline `value` times: the full 35.127 GFLOP per ViT-B/16 image of SURVEY.md section 8d). */
 #define TAPCLIP_FLAG_PRUNE_LAST_BLOCK 1
 int tapclip_tower_set_flag(tapclip_tower_t* tower, int32_t flag, int32_t value);

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(512) void gemm_mx8_kernel(Mx8GemmArgs g) {
     } else {
       s_base = g.W_scale;
       s_off = (uint32_t)((n0 + 8 * c) * 2);
-      s_step = (int64_t)g.N * 2;
+      s_step = (int64_t)(g.w_scale_rows > 0 ? g.w_scale_rows : g.N) * 2;
     }
   };
   auto stage_dma = [&](int st, int ks, const uint32_t (&a_off)[2], const uint32_t (&w_off)[2], uint32_t s_off, const uint8_t* s_base,

@@ -58,7 +58,8 @@ struct Mx8GemmArgs {
   const uint8_t* A_scale;  // [K/64][m_pad][2]
   int64_t lda, m_pad;      // m_pad: multiple of 8, >= M
   const uint8_t* W;        // [N, K] e4m3, row stride K
-  const uint8_t* W_scale;  // [K/64][N][2]
+  const uint8_t* W_scale;  // [K/64][N][2]  (a row range of a larger weight: [K/64][w_scale_rows][2], see w_scale_rows)
+  int32_t w_scale_rows = 0; // row count of the scale plane W_scale points into (0 = N): lets W / W_scale address rows r0 .. r0 + N - 1 of a taller matrix
   const float* bias;       // [N] or nullptr
   int64_t M;
   int32_t N, K;

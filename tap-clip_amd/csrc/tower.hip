@@ -376,12 +376,13 @@ int gemm(tapclip_tower* t, int slot, int epi, const bf16_t* a_hi, const bf16_t* 
 }
 
 int gemm_mx8(tapclip_tower* t, int slot, int epi, const uint8_t* a_q, const uint8_t* a_s, int64_t m_pad, const PackedMx8& w,
-             const float* bias, int64_t M, int N, int K, bf16_t* o_bf16, uint8_t* o_q, uint8_t* o_s, hipStream_t s) {
+             const float* bias, int64_t M, int N, int K, bf16_t* o_bf16, uint8_t* o_q, uint8_t* o_s, hipStream_t s, int64_t ldo = 0,
+             int w_scale_rows = 0) {
   Mx8GemmArgs g;
   g.A = a_q; g.A_scale = a_s; g.lda = K; g.m_pad = m_pad;
-  g.W = w.q; g.W_scale = w.s; g.bias = bias;
+  g.W = w.q; g.W_scale = w.s; g.w_scale_rows = w_scale_rows; g.bias = bias;
   g.M = M; g.N = N; g.K = K;
-  g.out_bf16 = o_bf16; g.out_q = o_q; g.out_q_scale = o_s; g.out_m_pad = m_pad; g.ldo = N;
+  g.out_bf16 = o_bf16; g.out_q = o_q; g.out_q_scale = o_s; g.out_m_pad = m_pad; g.ldo = ldo > 0 ? ldo : N;
   g.act = t->cfg.act;
   g.group_m = group_m_mx8_for(slot);
   ProfScope ps(t, slot, s);
@@ -393,7 +394,11 @@ int gemm_mx8(tapclip_tower* t, int slot, int epi, const uint8_t* a_q, const uint
 // block-scaled MXFP8 MFMA.  Their A operands are quantised where they are produced -- LayerNorm (layernorm.hip
 // MODE 3), the attention core's output (attention.hip store_o_mx8), the GELU epilogue of c_fc (gemm_mx8.hip) --
 // q|k|v and the two residual branches stay bf16, the residual stream fp32.
-int run_blocks_fp8(tapclip_tower* t, int64_t n_seq, int tokens, const Workspace& w, hipStream_t s) {
+int run_last_block_pooled(tapclip_tower* t, float* x, int64_t n_seq, int tokens, const Workspace& w, float* pooled_out, bf16_t** pooled_d_hi,
+                          bf16_t** pooled_d_lo, hipStream_t s);
+
+int run_blocks_fp8(tapclip_tower* t, int64_t n_seq, int tokens, const Workspace& w, hipStream_t s, float* pooled_out = nullptr,
+                   bf16_t** pooled_d_hi = nullptr, bf16_t** pooled_d_lo = nullptr) {
   const int64_t M = n_seq * tokens;
   const int D = t->cfg.width, F = t->cfg.mlp_dim, H = t->cfg.heads;
   int rc;
@@ -404,6 +409,8 @@ int run_blocks_fp8(tapclip_tower* t, int64_t n_seq, int tokens, const Workspace&
       // block l > 0: x still lacks BOTH branches of block l - 1 (its LN2 did not write x back)
       HIP_TRY(launch_layernorm_mx8(li == 0 ? 0 : 3, nullptr, w.x16, w.a_hi, w.d_hi, L.ln1_g, L.ln1_b, M, D, w.xn_q, w.xn_s, w.m_pad, s));
     }
+    if (li == t->cfg.layers - 1 && pooled_out != nullptr)  // CLS-only last block (see run_blocks)
+      return run_last_block_pooled(t, nullptr, n_seq, tokens, w, pooled_out, pooled_d_hi, pooled_d_lo, s);
     if ((rc = gemm_mx8(t, 2, EPI_BIAS_BF16, w.xn_q, w.xn_s, w.m_pad, L.qqkv, L.bqkv, M, 3 * D, D, w.qkv_hi, nullptr, nullptr, s))) return rc;
     {
       AttnArgs a;
@@ -526,10 +533,28 @@ int run_last_block_pooled(tapclip_tower* t, float* x, int64_t n_seq, int tokens,
   bf16_t *h_hi = w.h_hi, *h_lo = w.h_lo;        // [n, F]   (after the attention core has read q)
   bf16_t *d_hi = w.qkv_hi, *d_lo = w.qkv_lo;    // [n, D]   (after the attention core has read k, v)
   // K and V of every token: rows D .. 3D - 1 of in_proj into columns D .. 3D - 1 of the q|k|v buffer
-  Packed wkv{L.wqkv.hi + (size_t)D * D, L.wqkv.lo ? L.wqkv.lo + (size_t)D * D : nullptr};
-  if ((rc = gemm(t, 2, EPI_BIAS_BF16, w.xn_hi, w.xn_lo, D, wkv, L.bqkv + D, M, 2 * D, D, w.qkv_hi + D, w.qkv_lo ? w.qkv_lo + D : nullptr,
-                 nullptr, 3 * D, s))) return rc;
+  if (t->fp8) {
+    // (MXFP8 operands: the weight's row range is addressed inside its full-height scale plane)
+    PackedMx8 wkv{L.qqkv.q + (size_t)D * D, L.qqkv.s + (size_t)D * 2};
+    if ((rc = gemm_mx8(t, 2, EPI_BIAS_BF16, w.xn_q, w.xn_s, w.m_pad, wkv, L.bqkv + D, M, 2 * D, D, w.qkv_hi + D, nullptr, nullptr, s, 3 * D, 3 * D)))
+      return rc;
+  } else {
+    Packed wkv{L.wqkv.hi + (size_t)D * D, L.wqkv.lo ? L.wqkv.lo + (size_t)D * D : nullptr};
+    if ((rc = gemm(t, 2, EPI_BIAS_BF16, w.xn_hi, w.xn_lo, D, wkv, L.bqkv + D, M, 2 * D, D, w.qkv_hi + D, w.qkv_lo ? w.qkv_lo + D : nullptr,
+                   nullptr, 3 * D, s))) return rc;
+  }
   ProfScope ps(t, 7, s);  // everything on the n_seq CLS rows is accounted to the pool / project slot
+  // fp8 precision: the block's LayerNorm wrote MXFP8 rows only, and the residual stream is 16-bit (w.x16): the CLS rows are
+  // gathered to fp32 first and normalised again in 16 bits for the (16-bit) skinny GEMMs of the pooled tail
+  const bf16_t* qa_hi = w.xn_hi;
+  const bf16_t* qa_lo = w.xn_lo;
+  int64_t qa_ld = (int64_t)tokens * D;
+  if (t->fp8) {
+    HIP_TRY(launch_gather_cls16(w.x16, nullptr, (int)n_seq, tokens, D, pooled_out, s));
+    HIP_TRY(launch_layernorm(pooled_out, D, L.ln1_g, L.ln1_b, n_seq, D, w.xn_hi, nullptr, nullptr, s));  // (xn_q is dead: K | V are done)
+    qa_lo = nullptr;
+    qa_ld = D;
+  }
   // Q of the CLS rows: A = row b * tokens of xn (row stride tokens * D)
   GemmArgs g;
   auto small_gemm = [&](int epi, const bf16_t* ah, const bf16_t* al, int64_t lda, const Packed& wt, const float* bias, int N, int K, bf16_t* oh,
@@ -557,11 +582,13 @@ int run_last_block_pooled(tapclip_tower* t, float* x, int64_t n_seq, int tokens,
     return launch_gemm(a, epi, t->split, s);
   };
   (void)g;
-  HIP_TRY(small_gemm(EPI_BIAS_BF16, w.xn_hi, w.xn_lo, (int64_t)tokens * D, L.wqkv, L.bqkv, D, D, q_hi, q_lo));
+  HIP_TRY(small_gemm(EPI_BIAS_BF16, qa_hi, qa_lo, qa_ld, L.wqkv, L.bqkv, D, D, q_hi, q_lo));
   HIP_TRY(launch_attention_pooled(q_hi, q_lo, w.qkv_hi, w.qkv_lo, ao_hi, ao_lo, (int)n_seq, tokens, H, D, t->split, s));
   HIP_TRY(small_gemm(EPI_BIAS_BF16, ao_hi, ao_lo, D, L.wo, L.bo, D, D, a_hi, a_lo));
   // the CLS rows of the residual stream -> fp32 [n, D], + out_proj's branch, LN2
-  if (x24) HIP_TRY(launch_gather_cls24(w.x24_hi, w.x24_lo, nullptr, (int)n_seq, tokens, D, pooled_out, s));
+  if (t->fp8) {
+    // (gathered above, before the CLS rows' LN1)
+  } else if (x24) HIP_TRY(launch_gather_cls24(w.x24_hi, w.x24_lo, nullptr, (int)n_seq, tokens, D, pooled_out, s));
   else HIP_TRY(hipMemcpy2DAsync(pooled_out, (size_t)D * 4, x, (size_t)tokens * D * 4, (size_t)D * 4, (size_t)n_seq, hipMemcpyDeviceToDevice, s));
   HIP_TRY(launch_add_layernorm(pooled_out, a_hi, a_lo, L.ln2_g, L.ln2_b, n_seq, D, xn_hi, xn_lo, s));
   HIP_TRY(small_gemm(EPI_BIAS_GELU_BF16, xn_hi, xn_lo, D, L.wfc, L.bfc, F, D, h_hi, h_lo));
@@ -804,6 +831,10 @@ int tapclip_tower_load_weight(tapclip_tower_t* t, const char* key_c, const float
       const int64_t rows = qkv ? 3 * D : fc ? F : D, cols = pr ? F : D;
       if (!shape_is(shape, ndim, {rows, cols})) return bad(("[" + std::to_string(rows) + "," + std::to_string(cols) + "]").c_str());
       rc = own_packed_mx8(t, src, rows, (int)cols, qkv ? D : 0, qkv ? qscale : 1.f, qkv ? &L.qqkv : fc ? &L.qfc : pr ? &L.qpr : &L.qo, s);
+      // the LAST block also keeps 16-bit copies: its CLS-only tail (run_last_block_pooled) runs the M = batch GEMMs of
+      // the pooled rows on the 16-bit skinny kernel (14 - 25 MB per tower; those rows then see no MXFP8 rounding at all)
+      if (!rc && li == t->cfg.layers - 1)
+        rc = own_packed(t, src, rows, (int)cols, (int)cols, qkv ? D : 0, qkv ? qscale : 1.f, qkv ? &L.wqkv : fc ? &L.wfc : pr ? &L.wpr : &L.wo, s);
     }
     else if (sub == "attn.in_proj_weight") rc = mat(3 * D, D, &L.wqkv, &L.wqkv_t, D, qscale);
     else if (sub == "attn.in_proj_bias") rc = vec(3 * D, &L.bqkv, D, qscale);
@@ -897,15 +928,16 @@ int tapclip_encode_image(tapclip_tower_t* t, const float* images, int32_t B, flo
     else if (t->x24) HIP_TRY(launch_layernorm_x24(0, 1, w.x, D, w.x24_hi, w.x24_lo, nullptr, nullptr, t->lnpre_g, t->lnpre_b, t->layers[0].ln1_g, t->layers[0].ln1_b, (int64_t)B * N, D, w.xn_hi, s));
     else HIP_TRY(launch_layernorm(w.x, D, t->lnpre_g, t->lnpre_b, (int64_t)B * N, D, nullptr, nullptr, w.x, s));
   }
-  // CLS-only last block (not for the fp8 path, whose block GEMMs take MXFP8 operands; TAPCLIP_PRUNE_LAST=0 or
-  // tapclip_tower_set_flag(TAPCLIP_FLAG_PRUNE_LAST_BLOCK, 0) computes every row of every block)
-  const bool pooled = t->prune_last && !t->fp8 && t->cfg.layers >= 1;
+  // CLS-only last block (TAPCLIP_PRUNE_LAST=0 or tapclip_tower_set_flag(TAPCLIP_FLAG_PRUNE_LAST_BLOCK, 0) computes every
+  // row of every block)
+  const bool pooled = t->prune_last && t->cfg.layers >= 1;
   if (pooled) {
-    // CLS rows of the output: fp32 [B, D].  With the 24-bit planes the fp32 buffer w.x is free; with an fp32 residual
-    // stream (w.x live) they go to the front of the pending-branch buffer w.d, which LN1 of the last block has consumed.
-    float* cls = t->x24 ? w.x : reinterpret_cast<float*>(w.d_hi);
+    // CLS rows of the output: fp32 [B, D].  With the 24-bit planes or the fp8 path's 16-bit stream the fp32 buffer w.x is
+    // free; with an fp32 residual stream (w.x live) they go to the front of the pending-branch buffer w.d, which LN1 of
+    // the last block has consumed.
+    float* cls = (t->x24 || t->fp8) ? w.x : reinterpret_cast<float*>(w.d_hi);
     bf16_t *pd_hi = nullptr, *pd_lo = nullptr;
-    rc = run_blocks(t, w.x, B, N, 0, w, nullptr, nullptr, s, false, cls, &pd_hi, &pd_lo);
+    rc = t->fp8 ? run_blocks_fp8(t, B, N, w, s, cls, &pd_hi, &pd_lo) : run_blocks(t, w.x, B, N, 0, w, nullptr, nullptr, s, false, cls, &pd_hi, &pd_lo);
     if (rc) return rc;
     ProfScope ps(t, 7, s);
     HIP_TRY(launch_pool_project(cls, pd_hi, pd_lo, B, 1, D, nullptr, 0, t->lnpost_g, t->lnpost_b, t->proj, t->cfg.embed_dim, normalize, out, s));

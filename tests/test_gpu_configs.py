@@ -511,7 +511,10 @@ def test_pruned_last_block_equals_the_full_computation(eng, name, batch):
     cfg = configs.get_config(name)
     sd = synth.make_state_dict(cfg, seed=2, text=False)
     images = synth.make_images(batch, cfg, 11).to(DEV)
-    for precision, tol in (("bf16x3", 1e-5), ("fp16", 2e-4), ("bf16", 1.5e-3)):
+    # fp8 (widths the MXFP8 GEMM takes): the pooled rows' last block runs on 16-bit copies of that block's weights, so
+    # against the all-MXFP8 computation they differ by one block's MXFP8 rounding of the CLS row (4 % per GEMM: section 2)
+    modes = [("bf16x3", 1e-5), ("fp16", 2e-4), ("bf16", 1.5e-3)] + ([("fp8", 3e-2)] if cfg.vision.width % 256 == 0 else [])
+    for precision, tol in modes:
         full = eng.VisionTower(cfg, sd, DEV, precision, prune_last_block=False)
         pruned = eng.VisionTower(cfg, sd, DEV, precision)  # the default
         a = full.encode_image(images, normalize=True)

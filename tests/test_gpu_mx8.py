@@ -113,7 +113,9 @@ def _one_block_vision(eng, d, heads, mlp, seed, precision):
         sd[f"visual.{k}.weight"] = 1.0 + 0.1 * torch.randn(d, generator=g)
         sd[f"visual.{k}.bias"] = 0.05 * torch.randn(d, generator=g)
     sd["visual.proj"] = torch.randn(d, 64, generator=g) * d ** -0.5
-    return cfg, sd, eng.VisionTower(cfg, sd, DEV, precision)
+    # prune_last_block=False: this ONE block is the last block, and the library default would run its CLS rows through the
+    # 16-bit pooled tail -- these tests are about the MXFP8 block itself
+    return cfg, sd, eng.VisionTower(cfg, sd, DEV, precision, prune_last_block=False)
 
 
 @pytest.mark.parametrize("d,heads,mlp", [(768, 12, 3072), (1024, 16, 4096)])
@@ -221,7 +223,7 @@ def test_fp8_flash_attention_path_vit_l14_geometry(eng):
         sd[f"visual.{k}.weight"] = 1.0 + 0.1 * torch.randn(d, generator=g)
         sd[f"visual.{k}.bias"] = 0.05 * torch.randn(d, generator=g)
     sd["visual.proj"] = torch.randn(d, 64, generator=g) * d ** -0.5
-    tower = eng.VisionTower(cfg, sd, DEV, "fp8")
+    tower = eng.VisionTower(cfg, sd, DEV, "fp8", prune_last_block=False)  # (one block = the last block: keep it on MXFP8)
     images = synth.make_images(3, cfg, 11)
     got = tower.encode_image(images.to(DEV)).cpu()
     ocfg = clip_ref.ClipDims("blk8l", 64, 336, 14, clip_ref.TowerDims(d, 1, heads, mlp), clip_ref.TowerDims(128, 1, 2, 256), vocab=16, ctx=8)
