@@ -325,10 +325,16 @@ __global__ __launch_bounds__(256) void pool_project_bwd_kernel(const float* __re
   const int64_t roff = (n * tokens + tok) * (int64_t)K;
   for (int c = tid; c < K; c += 256) row[c] = hidden[roff + c];
   __syncthreads();
+  // (eight independent partial sums: one dependent chain of K loads from L2 was 25 us of this kernel's 63)
   for (int e = tid; e < E; e += 256) {
-    float s = 0.f;
-    for (int kk = 0; kk < K; ++kk) s = fmaf(row[kk], proj[(int64_t)kk * E + e], s);
-    y[e] = s;
+    float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int kk = 0;
+    for (; kk + 8 <= K; kk += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s8[u] = fmaf(row[kk + u], proj[(int64_t)(kk + u) * E + e], s8[u]);
+    }
+    for (; kk < K; ++kk) s8[0] = fmaf(row[kk], proj[(int64_t)kk * E + e], s8[0]);
+    y[e] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
   }
   __syncthreads();
   if (normalize) {
@@ -352,11 +358,25 @@ __global__ __launch_bounds__(256) void pool_project_bwd_kernel(const float* __re
     for (int e = tid; e < E; e += 256) dy[e] = dt[n * E + e];
   }
   __syncthreads();
+  // dp[c] = <dy, proj[c, :]>: a thread per row, 16-byte loads of its row, eight independent partial sums.  (Measured: 52.6 us
+  // for the kernel against 63.2 with one dependent chain; 16 lanes per row + a 4-step xor reduction 60.3; a wave per row
+  // 155.  With one 256-thread block per sequence the kernel is bound by its CU's L2 path: every block reads the whole
+  // projection matrix twice.)
   for (int c = tid; c < K; c += 256) {
-    float s = 0.f;
     const float* pr = proj + (int64_t)c * E;
-    for (int e = 0; e < E; ++e) s = fmaf(dy[e], pr[e], s);
-    d_hidden[roff + c] = s;
+    float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int e = 0;
+    if ((E & 7) == 0 && (reinterpret_cast<uintptr_t>(pr) & 15) == 0) {
+      for (; e + 8 <= E; e += 8) {
+        const float4 p0 = *reinterpret_cast<const float4*>(pr + e), p1 = *reinterpret_cast<const float4*>(pr + e + 4);
+        s8[0] = fmaf(dy[e], p0.x, s8[0]); s8[1] = fmaf(dy[e + 1], p0.y, s8[1]);
+        s8[2] = fmaf(dy[e + 2], p0.z, s8[2]); s8[3] = fmaf(dy[e + 3], p0.w, s8[3]);
+        s8[4] = fmaf(dy[e + 4], p1.x, s8[4]); s8[5] = fmaf(dy[e + 5], p1.y, s8[5]);
+        s8[6] = fmaf(dy[e + 6], p1.z, s8[6]); s8[7] = fmaf(dy[e + 7], p1.w, s8[7]);
+      }
+    }
+    for (; e < E; ++e) s8[0] = fmaf(dy[e], pr[e], s8[0]);
+    d_hidden[roff + c] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
   }
 }
 
@@ -366,9 +386,15 @@ __global__ __launch_bounds__(256) void logits_bwd_txt_kernel(const float* __rest
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)C * E) return;
   const int c = (int)(i / E), e = (int)(i - (int64_t)c * E);
-  float s = 0.f;
-  for (int b = 0; b < B; ++b) s = fmaf(dl[(int64_t)b * C + c], img[(int64_t)b * E + e], s);
-  d_txt[i] = scale * s;
+  // (eight independent partial sums instead of one dependent chain of B loads: 55 -> ~12 us at B = 256)
+  float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int b = 0;
+  for (; b + 8 <= B; b += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s8[u] = fmaf(dl[(int64_t)(b + u) * C + c], img[(int64_t)(b + u) * E + e], s8[u]);
+  }
+  for (; b < B; ++b) s8[0] = fmaf(dl[(int64_t)b * C + c], img[(int64_t)b * E + e], s8[0]);
+  d_txt[i] = scale * (((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7])));
 }
 __global__ __launch_bounds__(256) void dot_reduce_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                          int64_t n, float* out) {

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
           up[2] += bf2f((bf16_t)(ul.y & 0xFFFF)); up[3] += bf2f((bf16_t)(ul.y >> 16));
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (g.act == 0 ? gelu_erf_grad(v[e]) : gelu_quick_grad(v[e])) * up[e];
+        for (int e = 0; e < 4; ++e) v[e] = (g.act == 0 ? (SPLIT ? gelu_erf_grad(v[e]) : gelu_fit_grad(v[e])) : gelu_quick_grad(v[e])) * up[e];
       }
       if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_GELU_BWD_BF16) {
         bf16_t h[4], l[4];
