@@ -53,6 +53,36 @@ __device__ __forceinline__ f32x4_t mfma4(float a, float b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// ---- 16-bit operand fragments of v_mfma_f32_16x16x32 (lane (lr, lq) holds A[row lr][k = 8 lq + j] / B[k = 8 lq + j][col lr],
+// j = 0..7) for the H16 variant of the kernel below.
+typedef uint32_t bwd_u32x4_t __attribute__((ext_vector_type(4)));
+// eight consecutive elements of one LDS row (4-byte aligned: the 16-bit operand rows are 33 dwords)
+__device__ __forceinline__ bf16x8_t frag_row16(const bf16_t* p) {
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(p);
+  const bwd_u32x4_t v = {w[0], w[1], w[2], w[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+// eight elements of one LDS COLUMN (rows k0 .. k0 + 7 at stride ld); rows >= kmax read as zero
+__device__ __forceinline__ bf16x8_t frag_col16(const bf16_t* base, int k0, int ld, int col, int kmax) {
+  s16x8_t v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (k0 + j < kmax) ? (short)base[(k0 + j) * ld + col] : (short)0;
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+// eight fp32 values as a (hi, lo) pair of 16-bit fragments: hi + lo carries 16 significand bits of each
+__device__ __forceinline__ void frag_split16(const float (&v)[8], bf16x8_t& hi, bf16x8_t& lo) {
+  s16x8_t h, l;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    bf16_t hh, ll;
+    split_bf(v[j], hh, ll);
+    h[j] = (short)hh;
+    l[j] = (short)ll;
+  }
+  hi = __builtin_bit_cast(bf16x8_t, h);
+  lo = __builtin_bit_cast(bf16x8_t, l);
+}
+
 template <int NT, bool H16>  // NT = Tp / 16 key / query tiles: compile-time trip counts, so the LDS reads of a product pipeline
 __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs a) {
   extern __shared__ float sh[];
@@ -143,13 +173,22 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs a) {
   for (int tile = wave; tile < nt * nt; tile += NW) {
     const int ti = tile / nt, tj = tile - ti * nt;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    const op_t* qa = bufA + (ti * 16 + lr) * LDO + lq;
-    const op_t* kb = bufB + (tj * 16 + lr) * LDO + lq;
-    float av[16], bv[16];  // all operands of the tile first, then the MFMA chain: one LDS wait instead of sixteen
+    if constexpr (H16) {
+      // q and k are exact 16-bit values: two K = 32 MFMAs give the same products as the sixteen f32 ones (fp32 accumulation)
+      const bf16_t* qa = bufA + (ti * 16 + lr) * LDO + 8 * lq;
+      const bf16_t* kb = bufB + (tj * 16 + lr) * LDO + 8 * lq;
+      const bf16x8_t a0 = frag_row16(qa), a1 = frag_row16(qa + 32), b0 = frag_row16(kb), b1 = frag_row16(kb + 32);
+      acc = TAPCLIP_MFMA_16x16x32(a0, b0, acc);
+      acc = TAPCLIP_MFMA_16x16x32(a1, b1, acc);
+    } else {
+      const op_t* qa = bufA + (ti * 16 + lr) * LDO + lq;
+      const op_t* kb = bufB + (tj * 16 + lr) * LDO + lq;
+      float av[16], bv[16];  // all operands of the tile first, then the MFMA chain: one LDS wait instead of sixteen
 #pragma unroll
-    for (int u = 0; u < 16; ++u) { av[u] = ld(qa, 4 * u); bv[u] = ld(kb, 4 * u); }
+      for (int u = 0; u < 16; ++u) { av[u] = ld(qa, 4 * u); bv[u] = ld(kb, 4 * u); }
 #pragma unroll
-    for (int u = 0; u < 16; ++u) acc = mfma4(av[u], bv[u], acc);
+      for (int u = 0; u < 16; ++u) acc = mfma4(av[u], bv[u], acc);
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int i = ti * 16 + 4 * lq + e, j = tj * 16 + lr;
@@ -202,11 +241,26 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs a) {
   for (int tile = wave; tile < nt * 4; tile += NW) {
     const int tj = tile >> 2, td = tile & 3;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    float av[Tp / 4], bv[Tp / 4];
+    if constexpr (H16) {
+      // A = P^T as a (hi, lo) pair of 16-bit fragments (P is fp32: 2^-17 per element after the split), B = dO (exact)
 #pragma unroll
-    for (int u = 0; u < Tp / 4; ++u) { av[u] = P[(4 * u + lq) * LP + tj * 16 + lr]; bv[u] = ld(bufA, (4 * u + lq) * LDO + td * 16 + lr); }
+      for (int k0 = 0; k0 < Tp; k0 += 32) {
+        float pv[8];
 #pragma unroll
-    for (int u = 0; u < Tp / 4; ++u) acc = mfma4(av[u], bv[u], acc);
+        for (int j = 0; j < 8; ++j) pv[j] = (k0 + 8 * lq + j < Tp) ? P[(k0 + 8 * lq + j) * LP + tj * 16 + lr] : 0.f;
+        bf16x8_t ah, al;
+        frag_split16(pv, ah, al);
+        const bf16x8_t b = frag_col16(bufA, k0 + 8 * lq, LDO, td * 16 + lr, Tp);
+        acc = TAPCLIP_MFMA_16x16x32(ah, b, acc);
+        acc = TAPCLIP_MFMA_16x16x32(al, b, acc);
+      }
+    } else {
+      float av[Tp / 4], bv[Tp / 4];
+#pragma unroll
+      for (int u = 0; u < Tp / 4; ++u) { av[u] = P[(4 * u + lq) * LP + tj * 16 + lr]; bv[u] = ld(bufA, (4 * u + lq) * LDO + td * 16 + lr); }
+#pragma unroll
+      for (int u = 0; u < Tp / 4; ++u) acc = mfma4(av[u], bv[u], acc);
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int j = tj * 16 + 4 * lq + e;
@@ -220,13 +274,21 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs a) {
   for (int tile = wave; tile < nt * nt; tile += NW) {
     const int ti = tile / nt, tj = tile - ti * nt;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    const op_t* oa = bufA + (ti * 16 + lr) * LDO + lq;
-    const op_t* vb = bufB + (tj * 16 + lr) * LDO + lq;
-    float av[16], bv[16];
+    if constexpr (H16) {
+      const bf16_t* oa = bufA + (ti * 16 + lr) * LDO + 8 * lq;
+      const bf16_t* vb = bufB + (tj * 16 + lr) * LDO + 8 * lq;
+      const bf16x8_t a0 = frag_row16(oa), a1 = frag_row16(oa + 32), b0 = frag_row16(vb), b1 = frag_row16(vb + 32);
+      acc = TAPCLIP_MFMA_16x16x32(a0, b0, acc);
+      acc = TAPCLIP_MFMA_16x16x32(a1, b1, acc);
+    } else {
+      const op_t* oa = bufA + (ti * 16 + lr) * LDO + lq;
+      const op_t* vb = bufB + (tj * 16 + lr) * LDO + lq;
+      float av[16], bv[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) { av[u] = ld(oa, 4 * u); bv[u] = ld(vb, 4 * u); }
+      for (int u = 0; u < 16; ++u) { av[u] = ld(oa, 4 * u); bv[u] = ld(vb, 4 * u); }
 #pragma unroll
-    for (int u = 0; u < 16; ++u) acc = mfma4(av[u], bv[u], acc);
+      for (int u = 0; u < 16; ++u) acc = mfma4(av[u], bv[u], acc);
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int i = ti * 16 + 4 * lq + e, j = tj * 16 + lr;
@@ -243,16 +305,34 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs a) {
     const int tl = is_dk ? tile - nt * 4 : tile;
     const int tr = tl >> 2, td = tl & 3;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    float av[Tp / 4], bv[Tp / 4];
-    if (!is_dk) {
+    if constexpr (H16) {
+      // A = dS (dq) or dS^T (dk) as (hi, lo) 16-bit fragments, B = k or q (exact)
 #pragma unroll
-      for (int u = 0; u < Tp / 4; ++u) { av[u] = P[(tr * 16 + lr) * LP + 4 * u + lq]; bv[u] = ld(bufB, (4 * u + lq) * LDO + td * 16 + lr); }
+      for (int k0 = 0; k0 < Tp; k0 += 32) {
+        float pv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int kk = k0 + 8 * lq + j;
+          pv[j] = kk < Tp ? (is_dk ? P[kk * LP + tr * 16 + lr] : P[(tr * 16 + lr) * LP + kk]) : 0.f;
+        }
+        bf16x8_t ah, al;
+        frag_split16(pv, ah, al);
+        const bf16x8_t b = frag_col16(is_dk ? bufA : bufB, k0 + 8 * lq, LDO, td * 16 + lr, Tp);
+        acc = TAPCLIP_MFMA_16x16x32(ah, b, acc);
+        acc = TAPCLIP_MFMA_16x16x32(al, b, acc);
+      }
     } else {
+      float av[Tp / 4], bv[Tp / 4];
+      if (!is_dk) {
 #pragma unroll
-      for (int u = 0; u < Tp / 4; ++u) { av[u] = P[(4 * u + lq) * LP + tr * 16 + lr]; bv[u] = ld(bufA, (4 * u + lq) * LDO + td * 16 + lr); }
+        for (int u = 0; u < Tp / 4; ++u) { av[u] = P[(tr * 16 + lr) * LP + 4 * u + lq]; bv[u] = ld(bufB, (4 * u + lq) * LDO + td * 16 + lr); }
+      } else {
+#pragma unroll
+        for (int u = 0; u < Tp / 4; ++u) { av[u] = P[(4 * u + lq) * LP + tr * 16 + lr]; bv[u] = ld(bufA, (4 * u + lq) * LDO + td * 16 + lr); }
+      }
+#pragma unroll
+      for (int u = 0; u < Tp / 4; ++u) acc = mfma4(av[u], bv[u], acc);
     }
-#pragma unroll
-    for (int u = 0; u < Tp / 4; ++u) acc = mfma4(av[u], bv[u], acc);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int rr = tr * 16 + 4 * lq + e;
