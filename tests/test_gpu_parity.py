@@ -429,6 +429,28 @@ def test_text_backward_real_dims_vs_oracle_autograd(eng, precision):
     assert rel_max(gx[:, :16], xr.grad[:, :16]) < tol  # the context-token rows FullModel uses
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("T", [5, 20, 40, 49, 70, 96])
+def test_text_backward_every_sequence_length_class_vs_oracle_autograd(eng, precision, T):
+    """The attention backward is instantiated per number of 16-key tiles (1..6): one sequence length in each class,
+    including the odd ones (T = 5, 40, 70: the 16-bit variant's 32-deep MFMA steps run past the padded length there and
+    must read zeros), through the 2-block tiny text tower against torch autograd through the CPU oracle.  Reference:
+    the dX path of train.py:99-105 through models/model_wrapper.py:72-75."""
+    cfg = configs.get_config("tiny")
+    sd = synth.make_state_dict(cfg, seed=5, vision=False)
+    tower = eng.TextTower(cfg, sd, DEV, precision)
+    n, D = 3, cfg.text.width
+    x = synth.normal([n, T, D], 6, f"bwdT.x{T}")
+    g = synth.normal([n, T, D], 6, f"bwdT.g{T}")
+    xr = x.clone().requires_grad_(True)
+    hidden, _, _ = clip_ref.text_transformer_raw(xr, sd, clip_ref.CONFIGS["tiny"])
+    (hidden * g).sum().backward()
+    gx = tower.backward(x.to(DEV), g.to(DEV)).cpu()
+    _report(f"text backward tiny T={T} {precision} dL/dx", gx, xr.grad)
+    assert torch.isfinite(gx).all()
+    assert rel_l2(gx, xr.grad) < (TOL if precision == "bf16x3" else 1e-2)  # measured 2.2e-3 .. 3.9e-3 (bf16), 4e-6 .. 6e-6 (bf16x3)
+
+
 def test_text_backward_saved_equals_recompute(eng):
     """`forward_saved` + `backward_saved` (what a training step uses) against `forward` + the recomputing `backward`."""
     cfg = configs.get_config("tiny")
