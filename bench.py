@@ -590,18 +590,52 @@ def main():
                     engine.logits(tw.encode_image(images, normalize=True), text_feat, scale)
                 torch.cuda.synchronize(dev)
                 row["img_per_s_default_path"] = round(args.batch * its / (time.perf_counter() - t1), 1)
+                with contextlib.redirect_stdout(sys.stderr):
+                    fm = FullModel(names, cw, prompt_len=args.prompt_len, class_specific=True).eval()
+                for c, t in zip(names, ctx_bank):
+                    fm.prompt_learner.context_bank[c].copy_(t)
+                if not args.no_full_forward:
+                    # the whole FullModel forward and the prompt-tuning step in THIS precision (the `full_forward` /
+                    # `train_step` objects above are the headline precision's; "fp16", the library default, runs its
+                    # text tower -- forward and backward -- in split-bf16: three MFMA products per GEMM)
+                    n_ff = 3 if prec == "bf16x3" else 5
+                    for _ in range(2):
+                        fm(images)
+                    torch.cuda.synchronize(dev)
+                    t1 = time.perf_counter()
+                    for _ in range(n_ff):
+                        fm(images)
+                    torch.cuda.synchronize(dev)
+                    row["full_forward_ms"] = round(1e3 * (time.perf_counter() - t1) / n_ff, 3)
+                    with torch.enable_grad():
+                        labels_p = synth.make_labels(args.batch, args.classes).to(dev)
+                        opt_p = torch.optim.AdamW(fm.prompt_learner.parameters(), lr=0.0, weight_decay=0.0)  # (lr 0: the
+                        fm.train()                                                  # logits check below sees the same prompts)
+
+                        def step_p():
+                            out_p = fm(images, labels_p)
+                            opt_p.zero_grad(set_to_none=True)
+                            out_p["loss"].backward()
+                            opt_p.step()
+
+                        for _ in range(2):
+                            step_p()
+                        torch.cuda.synchronize(dev)
+                        t1 = time.perf_counter()
+                        for _ in range(n_ff):
+                            step_p()
+                        torch.cuda.synchronize(dev)
+                        row["train_step_ms"] = round(1e3 * (time.perf_counter() - t1) / n_ff, 3)
+                        fm.eval()
+                        del opt_p
                 if oracle_logits is not None:
-                    with contextlib.redirect_stdout(sys.stderr):
-                        fm = FullModel(names, cw, prompt_len=args.prompt_len, class_specific=True).eval()
-                    for c, t in zip(names, ctx_bank):
-                        fm.prompt_learner.context_bank[c].copy_(t)
                     lg = fm(images[:n_ref])["logits"].cpu()
                     err = (lg - oracle_logits).abs()
                     row["logits_rel_max_vs_cpu_oracle"] = float("%.3e" % float(err.max() / oracle_logits.abs().max()))
                     row["logits_rel_l2_vs_cpu_oracle"] = float("%.3e" % float(err.norm() / oracle_logits.norm()))
                     row["meets_1e-3"] = bool(err.max() / oracle_logits.abs().max() < 1e-3)
                     row["top1_agreement_vs_cpu_oracle"] = round(float((lg.argmax(1) == oracle_logits.argmax(1)).float().mean()), 4)
-                    del fm
+                del fm
                 table[prec] = row
                 print(f"[bench] precision {prec} done at {time.perf_counter() - t_start:.1f}s", file=sys.stderr, flush=True)
                 if not own:
@@ -614,6 +648,7 @@ def main():
             result["parity_mode"] = {"precision": best, "img_per_s": table[best]["img_per_s"],
                                      "encoder_mfma_frac": table[best]["encoder_mfma_frac"],
                                      "img_per_s_default_path": table[best].get("img_per_s_default_path"),
+                                     "full_forward_ms": table[best].get("full_forward_ms"), "train_step_ms": table[best].get("train_step_ms"),
                                      "gemm_family": table[best].get("gemm_family"), "kernels": table[best].pop("kernels", None),
                                      "logits_rel_max_vs_cpu_oracle": table[best]["logits_rel_max_vs_cpu_oracle"],
                                      "logits_rel_l2_vs_cpu_oracle": table[best]["logits_rel_l2_vs_cpu_oracle"],
