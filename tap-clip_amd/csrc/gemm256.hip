@@ -551,7 +551,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 }
 
 // ---- fix-up of the K-split tail tiles: out = epilogue(bias + sum of the parts)
-template <int EPI, int BN>
+template <int EPI, int BN, bool SPLIT = false>
 __global__ __launch_bounds__(256) void splitk_fixup_kernel(GemmArgs g, int n_tiles) {
   const int tiles_n = g.N / BN;
   const int tiles_m = (int)((g.M + BM - 1) / BM);
@@ -573,10 +573,18 @@ __global__ __launch_bounds__(256) void splitk_fixup_kernel(GemmArgs g, int n_til
     v += *reinterpret_cast<const f32x4_t*>(g.split_ws + (size_t)(t * g.split_parts + p) * (BM * BN) + rr * BN + c4 * 4);
   if (EPI == EPI_BIAS_GELU_BF16) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = g.act == 0 ? gelu_fast16(v[e]) : gelu_quick(v[e]);
+    for (int e = 0; e < 4; ++e) v[e] = g.act == 0 ? (SPLIT ? gelu_erf(v[e]) : gelu_fast16(v[e])) : gelu_quick(v[e]);  // (as the GEMM's own epilogue)
   }
   if (EPI == EPI_BIAS_F32) {  // (the dX GEMMs of the prompt-tuning backward: fp32 gradients)
     *reinterpret_cast<f32x4_t*>(g.out_f32 + m * g.ldo + n) = v;
+    return;
+  }
+  if (SPLIT) {  // split-bf16 outputs: hi and lo planes
+    bf16_t h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_bf(v[e], h[e], l[e]);
+    *reinterpret_cast<uint2*>(g.out_hi + m * g.ldo + n) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+    *reinterpret_cast<uint2*>(g.out_lo + m * g.ldo + n) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
     return;
   }
   uint2 ph;
@@ -625,10 +633,13 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
   // K = 2048 on 256 CUs, 40 us): every tile is K-split (split_from = 0) and the grid grows to tiles x parts.
   // (EPI_BIAS_F32: the K = 1536 / 2048, N = 512 dX GEMMs of the text tower's backward -- one partial round of 48 - 96 tiles
   // and 48 - 64 dependent k-steps, 37.5 us; K-split two ways + the fix-up: see DESIGN.md section 6)
-  if (!SPLIT && (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_BIAS_F32) && a.split_ws != nullptr && !no_tail_split) {
+  // (split-bf16, round 3: only the second case -- EVERY tile of the launch split alike, so a row's bits depend on the
+  // launch's M and never on which rows share it; its three products are one K sequence of 3 K / 32 steps, cut anywhere.
+  // The text tower of the fp16 default mode at 65 classes: c_proj 192 dependent steps on 96 of 256 CUs.)
+  if ((EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_BIAS_F32) && a.split_ws != nullptr && !no_tail_split) {
     const int64_t full = tiles / n_cu, rem = tiles - full * n_cu;
-    const int ks = a.K / BKS;
-    if (rem > 0 && rem * 2 <= n_cu && (full == 0 || BN == 256)) {
+    const int ks = (SPLIT ? 3 : 1) * (a.K / BKS);
+    if (rem > 0 && rem * 2 <= n_cu && (full == 0 || (BN == 256 && !SPLIT))) {
       int parts = (int)(n_cu / rem);
       // a part shorter than ~16 K steps is all pipeline fill and drain: it costs more than the idle CUs
       static const int min_ks = [] {
@@ -647,7 +658,7 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
   if (b.split_parts > 0) {
     const int n_tail = (int)(tiles - b.split_from);
     if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_BIAS_F32)
-      hipLaunchKernelGGL((splitk_fixup_kernel<EPI, BN>), dim3((unsigned)(n_tail * (BM * BN / 4 / 256))), dim3(256), 0, s, b, n_tail);
+      hipLaunchKernelGGL((splitk_fixup_kernel<EPI, BN, SPLIT>), dim3((unsigned)(n_tail * (BM * BN / 4 / 256))), dim3(256), 0, s, b, n_tail);
   }
   return hipGetLastError();
 }

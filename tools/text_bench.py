@@ -10,7 +10,8 @@ from tap_clip_amd.models import CLIPWrapper, FullModel
 
 cfg = configs.get_config("ViT-B-16")
 sd = synth.make_state_dict(cfg, seed=2)
-clip = CLIPWrapper("ViT-B-16", None, "cuda", precision="bf16", attn_semantics="intended", state_dict=sd)
+prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"  # "fp16": the library default (split-bf16 text tower)
+clip = CLIPWrapper("ViT-B-16", None, "cuda", precision=prec, attn_semantics="intended", state_dict=sd)
 names = [f"class_{i}" for i in range(65)]
 with contextlib.redirect_stdout(sys.stderr):
     model = FullModel(names, clip, prompt_len=16, class_specific=True).eval()
@@ -23,4 +24,4 @@ with torch.no_grad():
     for _ in range(n):
         model.text_features()
     torch.cuda.synchronize()
-    print(f"text_features: {(time.perf_counter() - t) / n * 1e3:.3f} ms per call")
+    print(f"text_features [{prec}]: {(time.perf_counter() - t) / n * 1e3:.3f} ms per call")
