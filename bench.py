@@ -73,8 +73,14 @@ def source_sha16():
     import hashlib
 
     h = hashlib.sha256()
-    for f in ("gemm256.hip", "gemm_mx8.hip", "common.h", "kernels.h"):
-        h.update(open(os.path.join(ROOT, "tap-clip_amd", "csrc", f), "rb").read())
+    csrc = os.path.join(ROOT, "tap-clip_amd", "csrc")
+    for f in ("gemm256.hip", "gemm_mx8.hip", "common.h"):
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    # of kernels.h only what the GEMM kernels see: their argument structs (the rest declares other kernels' launchers)
+    text = open(os.path.join(csrc, "kernels.h")).read()
+    for name in ("struct GemmArgs {", "struct Mx8GemmArgs {"):
+        i = text.index(name)
+        h.update(text[i:text.index("};", i) + 2].encode())
     return h.hexdigest()[:16]
 
 

@@ -172,7 +172,7 @@ struct AttnBwdArgs {
 size_t attn_bwd_lds_bytes(int T);
 hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s);
 hipError_t launch_ln_bwd(const float* x, const float* gamma, const float* dy, int64_t rows, int32_t d, float* dres,
-                         hipStream_t s);
+                         bf16_t* pk_hi, bf16_t* pk_lo, hipStream_t s);  // pk_*: optional 16-bit planes of the updated dres
 hipError_t launch_pool_project_bwd(const float* hidden, int64_t n, int32_t tokens, int32_t K, int32_t tok,
                                    const float* proj, int32_t E, int32_t normalize, const float* dt, float* d_hidden,
                                    hipStream_t s);

@@ -670,17 +670,18 @@ int run_backward_sweep(tapclip_tower* t, float* dx, int64_t n_seq, int tokens, i
   const int D = t->cfg.width, F = t->cfg.mlp_dim, H = t->cfg.heads, L = t->cfg.layers;
   int rc;
   float* dn = w.x;
+  // (the 16-bit planes of dx that each branch's first GEMM reads are written by the LayerNorm backward that produced dx;
+  // only the gradient that enters the sweep is packed by its own pass)
+  HIP_TRY(launch_pack(dx, M, D, D, D, 0, 1.f, w.d_hi, w.d_lo, s));
   for (int li = L - 1; li >= 0; --li) {
     const LayerW& Lw = t->layers[li];
     // MLP branch: m = gelu(LN2(x1) Wfc^T + bfc) Wpr^T + bpr
-    HIP_TRY(launch_pack(dx, M, D, D, D, 0, 1.f, w.d_hi, w.d_lo, s));
     if ((rc = gemm(t, 6, EPI_BIAS_BF16, w.d_hi, w.d_lo, D, Lw.wpr_t, nullptr, M, F, D, w.h_hi, w.h_lo, nullptr, F, s))) return rc;
     HIP_TRY(launch_layernorm(sv.x1[li], D, Lw.ln2_g, Lw.ln2_b, M, D, w.xn_hi, w.xn_lo, nullptr, s));
     if ((rc = gemm(t, 5, EPI_GELU_BWD_BF16, w.xn_hi, w.xn_lo, D, Lw.wfc, Lw.bfc, M, F, D, w.h_hi, w.h_lo, nullptr, F, s, nullptr, 0, w.h_hi, w.h_lo))) return rc;
     if ((rc = gemm(t, 5, EPI_BIAS_F32, w.h_hi, w.h_lo, F, Lw.wfc_t, nullptr, M, D, F, nullptr, nullptr, dn, D, s))) return rc;
-    HIP_TRY(launch_ln_bwd(sv.x1[li], Lw.ln2_g, dn, M, D, dx, s));
+    HIP_TRY(launch_ln_bwd(sv.x1[li], Lw.ln2_g, dn, M, D, dx, w.d_hi, w.d_lo, s));
     // attention branch: a = attention(LN1(x0) Wqkv^T + b) Wo^T + bo
-    HIP_TRY(launch_pack(dx, M, D, D, D, 0, 1.f, w.d_hi, w.d_lo, s));
     if ((rc = gemm(t, 4, EPI_BIAS_BF16, w.d_hi, w.d_lo, D, Lw.wo_t, nullptr, M, D, D, w.ao_hi, w.ao_lo, nullptr, D, s))) return rc;
     AttnBwdArgs b;
     b.qkv_hi = sv.qkv_hi[li]; b.qkv_lo = sv.qkv_lo[li];
@@ -690,7 +691,7 @@ int run_backward_sweep(tapclip_tower* t, float* dx, int64_t n_seq, int tokens, i
     b.n_seq = (int)n_seq; b.T = tokens; b.H = H; b.D = D; b.causal = causal;
     HIP_TRY(launch_attention_bwd(b, s));
     if ((rc = gemm(t, 2, EPI_BIAS_F32, w.qkv_hi, w.qkv_lo, 3 * D, Lw.wqkv_t, nullptr, M, D, 3 * D, nullptr, nullptr, dn, D, s))) return rc;
-    HIP_TRY(launch_ln_bwd(sv.x0[li], Lw.ln1_g, dn, M, D, dx, s));
+    HIP_TRY(launch_ln_bwd(sv.x0[li], Lw.ln1_g, dn, M, D, dx, li > 0 ? w.d_hi : nullptr, li > 0 ? w.d_lo : nullptr, s));
   }
   return TAPCLIP_OK;
 }
