@@ -84,10 +84,11 @@ hipError_t launch_layernorm(const float* x, int64_t ldx, const float* gamma, con
                             int64_t rows, int32_t d, bf16_t* out_hi, bf16_t* out_lo, float* out_f32,
                             hipStream_t s, bool stream_x = false);
 
-// x += delta (bf16 hi [+ lo]) written back in fp32, then LayerNorm(x) -> bf16 hi [+ lo]
+// x += delta (bf16 hi [+ lo]) written back in fp32, then LayerNorm(x) -> bf16 hi [+ lo].  x_wb != nullptr: the updated
+// rows go to x_wb ([rows, d]) instead and x is left as it was
 hipError_t launch_add_layernorm(float* x, const bf16_t* delta_hi, const bf16_t* delta_lo, const float* gamma,
                                 const float* beta, int64_t rows, int32_t d, bf16_t* out_hi, bf16_t* out_lo,
-                                hipStream_t s);
+                                hipStream_t s, float* x_wb = nullptr);
 // add: 1 = x += d1 (written back); 2 = LayerNorm(x + d1), x NOT written back; 3 = x += d1 + d2 (written back)
 hipError_t launch_add_layernorm_ex(int add, float* x, const bf16_t* d1_hi, const bf16_t* d1_lo, const bf16_t* d2_hi,
                                    const bf16_t* d2_lo, const float* gamma, const float* beta, int64_t rows, int32_t d,

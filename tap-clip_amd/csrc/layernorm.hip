@@ -156,7 +156,12 @@ __global__ __launch_bounds__(256) void ln_vec_kernel(float* __restrict__ x, int6
         else if (NTX) {
           typedef float lf32x4_t __attribute__((ext_vector_type(4)));
           __builtin_nontemporal_store((lf32x4_t{v[j].x, v[j].y, v[j].z, v[j].w}), reinterpret_cast<lf32x4_t*>(xr + c));
-        } else *reinterpret_cast<float4*>(xr + c) = v[j];
+        } else {
+          // (MODE 0 / 1 have no fp32 LayerNorm output: out_f32 then names where the UPDATED residual row goes instead of
+          //  back into x -- the training forward keeps every block's residual for the backward without copying it)
+          float* xw = (MODE != 2 && out_f32 != nullptr) ? out_f32 + row * ldx : xr;
+          *reinterpret_cast<float4*>(xw + c) = v[j];
+        }
       }
     }
     s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
@@ -233,10 +238,11 @@ __global__ __launch_bounds__(256) void ln_generic_kernel(float* __restrict__ x, 
     }
     return t;
   };
+  float* xw = (MODE != 2 && out_f32 != nullptr) ? out_f32 + row * ldx : xr;  // (see ln_vec_kernel: the updated row's destination)
   if (ADD == 1 || ADD == 3) {  // each lane updates (and later re-reads) only its own elements
-    for (int c = lane; c < d; c += 64) xr[c] = val(c);
+    for (int c = lane; c < d; c += 64) xw[c] = val(c);
   }
-  auto cur = [&](int c) { return ADD == 2 ? val(c) : xr[c]; };
+  auto cur = [&](int c) { return ADD == 2 ? val(c) : (ADD == 0 ? xr[c] : xw[c]); };
   float s = 0.f;
   for (int c = lane; c < d; c += 64) s += cur(c);
   const float mean = wave_sum(s) / (float)d;
@@ -310,12 +316,13 @@ hipError_t launch_mode(float* x, int64_t ldx, const bf16_t* dh, const bf16_t* dl
 template <int MODE>
 hipError_t launch_add_mode(int add, float* x, const bf16_t* dh, const bf16_t* dl, const bf16_t* eh, const bf16_t* el, const float* gamma,
                            const float* beta, int64_t rows, int32_t d, bf16_t* hi, bf16_t* lo, hipStream_t s, uint8_t* q = nullptr,
-                           uint8_t* qs = nullptr, int64_t rows_pad = 0, bf16_t* x16 = nullptr, bool ntx = false) {
+                           uint8_t* qs = nullptr, int64_t rows_pad = 0, bf16_t* x16 = nullptr, bool ntx = false, float* x_wb = nullptr) {
+  if (x_wb != nullptr && (MODE > 1 || ntx || x16 != nullptr || (add != 1 && add != 3))) return hipErrorInvalidValue;
   switch (add) {
     case 0: return launch_mode<MODE, 0>(x, d, nullptr, nullptr, nullptr, nullptr, gamma, beta, rows, d, hi, lo, nullptr, s, q, qs, rows_pad, x16, ntx);
-    case 1: return launch_mode<MODE, 1>(x, d, dh, dl, nullptr, nullptr, gamma, beta, rows, d, hi, lo, nullptr, s, q, qs, rows_pad, x16, ntx);
+    case 1: return launch_mode<MODE, 1>(x, d, dh, dl, nullptr, nullptr, gamma, beta, rows, d, hi, lo, x_wb, s, q, qs, rows_pad, x16, ntx);
     case 2: return launch_mode<MODE, 2>(x, d, dh, dl, nullptr, nullptr, gamma, beta, rows, d, hi, lo, nullptr, s, q, qs, rows_pad, x16, ntx);
-    case 3: return launch_mode<MODE, 3>(x, d, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, nullptr, s, q, qs, rows_pad, x16, ntx);
+    case 3: return launch_mode<MODE, 3>(x, d, dh, dl, eh, el, gamma, beta, rows, d, hi, lo, x_wb, s, q, qs, rows_pad, x16, ntx);
     default: return hipErrorInvalidValue;
   }
 }
@@ -333,8 +340,11 @@ hipError_t launch_layernorm(const float* x, int64_t ldx, const float* gamma, con
 
 hipError_t launch_add_layernorm(float* x, const bf16_t* delta_hi, const bf16_t* delta_lo, const float* gamma,
                                 const float* beta, int64_t rows, int32_t d, bf16_t* out_hi, bf16_t* out_lo,
-                                hipStream_t s) {
-  return launch_add_layernorm_ex(1, x, delta_hi, delta_lo, nullptr, nullptr, gamma, beta, rows, d, out_hi, out_lo, s, false);
+                                hipStream_t s, float* x_wb) {
+  if (rows <= 0 || d <= 0 || d % 64 != 0 || delta_hi == nullptr) return hipErrorInvalidValue;
+  if (x_wb == nullptr) return launch_add_layernorm_ex(1, x, delta_hi, delta_lo, nullptr, nullptr, gamma, beta, rows, d, out_hi, out_lo, s, false);
+  if (out_lo != nullptr) return launch_add_mode<1>(1, x, delta_hi, delta_lo, nullptr, nullptr, gamma, beta, rows, d, out_hi, out_lo, s, nullptr, nullptr, 0, nullptr, false, x_wb);
+  return launch_add_mode<0>(1, x, delta_hi, nullptr, nullptr, nullptr, gamma, beta, rows, d, out_hi, nullptr, s, nullptr, nullptr, 0, nullptr, false, x_wb);
 }
 
 // add: 1 = x += d1 (written back); 2 = normalise x + d1 without writing x back; 3 = x += d1 + d2 (written back)

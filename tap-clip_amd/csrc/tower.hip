@@ -627,24 +627,21 @@ Saved carve_saved(const tapclip_tower* t, int64_t M, void* base) {
   return sv;
 }
 
-// Forward of the text tower again, keeping what the backward needs (activation recomputation keeps the C ABI
-// stateless: nothing is remembered between tapclip_text_forward and tapclip_text_backward), then the
-// backward sweep.  dx (fp32 [M, D]) enters holding dL/d(hidden) and leaves holding dL/d(x_in).
 // Forward of the blocks that keeps what the backward needs (sv): the residual stream before each LayerNorm, q|k|v and
-// the attention output of every block.  On return w.x holds x without the last c_proj branch, which is pending in w.d.
+// the attention output of every block.  The residual stream is not copied into sv: it MOVES through it -- every
+// add + LayerNorm reads the previous saved row block and writes the updated rows into the next one (x0[0] <- x_in,
+// x1[l] = x0[l] + attention branch, x0[l+1] = x1[l] + MLP branch); 25 device copies of [M, D] fp32 per call are gone.
+// On return *x_last = x1[L-1]: x without the last c_proj branch, which is pending in w.d.
 int run_forward_saving(tapclip_tower* t, const float* x_in, int64_t n_seq, int tokens, int causal, const Workspace& w,
-                       const Saved& sv, hipStream_t s) {
+                       const Saved& sv, hipStream_t s, const float** x_last) {
   const int64_t M = n_seq * tokens;
   const int D = t->cfg.width, F = t->cfg.mlp_dim, H = t->cfg.heads, L = t->cfg.layers;
-  float* x = w.x;
-  HIP_TRY(hipMemcpyAsync(x, x_in, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
-  auto keep = [&](float* dst) { return hipMemcpyAsync(dst, x, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s); };
+  HIP_TRY(hipMemcpyAsync(sv.x0[0], x_in, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
   int rc;
   for (int li = 0; li < L; ++li) {
     const LayerW& Lw = t->layers[li];
-    if (li == 0) HIP_TRY(launch_layernorm(x, D, Lw.ln1_g, Lw.ln1_b, M, D, w.xn_hi, w.xn_lo, nullptr, s));
-    else HIP_TRY(launch_add_layernorm(x, w.d_hi, w.d_lo, Lw.ln1_g, Lw.ln1_b, M, D, w.xn_hi, w.xn_lo, s));
-    HIP_TRY(keep(sv.x0[li]));
+    if (li == 0) HIP_TRY(launch_layernorm(sv.x0[0], D, Lw.ln1_g, Lw.ln1_b, M, D, w.xn_hi, w.xn_lo, nullptr, s));
+    else HIP_TRY(launch_add_layernorm(sv.x1[li - 1], w.d_hi, w.d_lo, Lw.ln1_g, Lw.ln1_b, M, D, w.xn_hi, w.xn_lo, s, sv.x0[li]));
     if ((rc = gemm(t, 2, EPI_BIAS_BF16, w.xn_hi, w.xn_lo, D, Lw.wqkv, Lw.bqkv, M, 3 * D, D, sv.qkv_hi[li], sv.qkv_lo[li], nullptr, 3 * D, s))) return rc;
     AttnArgs a;
     a.qkv_hi = sv.qkv_hi[li]; a.qkv_lo = sv.qkv_lo[li];
@@ -653,11 +650,11 @@ int run_forward_saving(tapclip_tower* t, const float* x_in, int64_t n_seq, int t
     a.n_seq = (int)n_seq; a.T = tokens; a.H = H; a.D = D; a.causal = causal;
     HIP_TRY(launch_attention(a, t->split, s));
     if ((rc = gemm(t, 4, EPI_BIAS_BF16, sv.ao_hi[li], sv.ao_lo[li], D, Lw.wo, Lw.bo, M, D, D, w.d_hi, w.d_lo, nullptr, D, s))) return rc;
-    HIP_TRY(launch_add_layernorm(x, w.d_hi, w.d_lo, Lw.ln2_g, Lw.ln2_b, M, D, w.xn_hi, w.xn_lo, s));
-    HIP_TRY(keep(sv.x1[li]));
+    HIP_TRY(launch_add_layernorm(sv.x0[li], w.d_hi, w.d_lo, Lw.ln2_g, Lw.ln2_b, M, D, w.xn_hi, w.xn_lo, s, sv.x1[li]));
     if ((rc = gemm(t, 5, EPI_BIAS_GELU_BF16, w.xn_hi, w.xn_lo, D, Lw.wfc, Lw.bfc, M, F, D, w.h_hi, w.h_lo, nullptr, F, s))) return rc;
     if ((rc = gemm(t, 6, EPI_BIAS_BF16, w.h_hi, w.h_lo, F, Lw.wpr, Lw.bpr, M, D, F, w.d_hi, w.d_lo, nullptr, D, s))) return rc;
   }
+  *x_last = sv.x1[L - 1];
   return TAPCLIP_OK;
 }
 
@@ -699,7 +696,8 @@ int run_backward_sweep(tapclip_tower* t, float* dx, int64_t n_seq, int tokens, i
 // Forward again (activation recomputation keeps tapclip_text_backward stateless), then the sweep.
 int run_backward(tapclip_tower* t, const float* x_in, float* dx, int64_t n_seq, int tokens, int causal,
                  const Workspace& w, const Saved& sv, hipStream_t s) {
-  int rc = run_forward_saving(t, x_in, n_seq, tokens, causal, w, sv, s);
+  const float* x_last = nullptr;
+  int rc = run_forward_saving(t, x_in, n_seq, tokens, causal, w, sv, s, &x_last);
   if (rc) return rc;
   return run_backward_sweep(t, dx, n_seq, tokens, causal, w, sv, s);
 }
@@ -1026,8 +1024,9 @@ int tapclip_text_forward_saved(tapclip_tower_t* t, const float* x_in, int32_t n_
   if (w.bytes > workspace_bytes) return fail(TAPCLIP_EWORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, w.bytes);
   const Saved sv = carve_saved(t, M, saved);
   if (sv.bytes > saved_bytes) return fail(TAPCLIP_EWORKSPACE, "saved buffer %zu B < required %zu B", saved_bytes, sv.bytes);
-  if ((rc = run_forward_saving(t, x_in, n_seq, tokens, causal, w, sv, s))) return rc;
-  HIP_TRY(hipMemcpyAsync(out_hidden, w.x, (size_t)M * t->cfg.width * 4, hipMemcpyDeviceToDevice, s));
+  const float* x_last = nullptr;
+  if ((rc = run_forward_saving(t, x_in, n_seq, tokens, causal, w, sv, s, &x_last))) return rc;
+  HIP_TRY(hipMemcpyAsync(out_hidden, x_last, (size_t)M * t->cfg.width * 4, hipMemcpyDeviceToDevice, s));
   HIP_TRY(launch_add_delta(out_hidden, w.d_hi, w.d_lo, M * t->cfg.width, s));  // last pending branch
   return TAPCLIP_OK;
 }
