@@ -255,6 +255,15 @@ void tapclip_comm_destroy(tapclip_comm_t* comm);
  * runs on 16-bit copies of that block's weights).  0 = compute every row of every block
  * (what bench.py's headline `value` times: the full 35.127 GFLOP per ViT-B/16 image of SURVEY.md section 8d). */
 #define TAPCLIP_FLAG_PRUNE_LAST_BLOCK 1
+/* TAPCLIP_FLAG_KSPLIT (both towers, default 1): when a GEMM launch ends in a partial round of tiles (c_proj at ViT-B/16,
+ * batch 256: 2.31 rounds of 256 workgroups) or has fewer tiles than half the CUs (the text tower at 65 classes), those
+ * tiles are K-split over the idle CUs and summed by a fix-up kernel: the launch finishes sooner, at MORE CU-time in total
+ * (more workgroups + the fix-up).  That is the right trade when the tower has the GPU to itself (the image encoder alone,
+ * the text backward) and the wrong one when another stream wants the idle CUs: with both towers of FullModel.forward in
+ * flight (reference models/model_wrapper.py:40-75) the whole forward is 12.7 ms with the splits and 12.2 ms without, so
+ * the Python FullModel switches it off for its forward and back on for the backward.  Results differ between the two
+ * settings by fp32 summation order only (the rounding-level dependence documented for the tail split). */
+#define TAPCLIP_FLAG_KSPLIT 2
 int tapclip_tower_set_flag(tapclip_tower_t* tower, int32_t flag, int32_t value);
 
 /* ---- per-stage timing (HIP events on `stream`) for bench.py's roofline object.

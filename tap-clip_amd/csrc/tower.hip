@@ -82,6 +82,7 @@ struct tapclip_tower {
   bool fp8 = false;       // TAPCLIP_PREC_FP8: block GEMMs on MXFP8 (image tower only)
   bool x24 = false;       // image tower, bf16 / IEEE-half modes: the residual stream of the blocks in 24-bit planes (layernorm.hip XF = 2)
   bool prune_last = true; // image tower: the last block computes K / V for every token but everything else for the CLS row only
+  bool ksplit = true;     // K-split the tiles of partial GEMM rounds over idle CUs (TAPCLIP_FLAG_KSPLIT)
   int tokens_vision = 0;  // G*G + 1
   int Kp = 0;             // padded 3*p*p
   std::vector<LayerW> layers;
@@ -360,7 +361,7 @@ int gemm(tapclip_tower* t, int slot, int epi, const bf16_t* a_hi, const bf16_t* 
     void* p = nullptr;
     if (dev_alloc(t, gemm256_split_ws_bytes(), &p) == TAPCLIP_OK) t->split_ws = static_cast<float*>(p);
   }
-  g.split_ws = t->split_ws;
+  g.split_ws = t->ksplit ? t->split_ws : nullptr;  // (TAPCLIP_FLAG_KSPLIT: 0 = no K-split of partial rounds -- least CU-time)
   g.A_hi = a_hi; g.A_lo = a_lo; g.lda = lda;
   g.W_hi = w.hi; g.W_lo = w.lo;
   g.bias = bias;
@@ -1308,6 +1309,7 @@ int tapclip_tower_set_flag(tapclip_tower_t* t, int32_t flag, int32_t value) {
   if (!t) return fail(TAPCLIP_EINVAL, "null tower");
   switch (flag) {
     case TAPCLIP_FLAG_PRUNE_LAST_BLOCK: t->prune_last = value != 0; return TAPCLIP_OK;
+    case TAPCLIP_FLAG_KSPLIT: t->ksplit = value != 0; return TAPCLIP_OK;
     default: return fail(TAPCLIP_EINVAL, "unknown tower flag %d", flag);
   }
 }

@@ -52,6 +52,11 @@ class _Tower:
     def _check(self, rc: int) -> None:
         _lib.check(rc, self.lib)  # the error text lives in the library variant that produced it
 
+    def set_ksplit(self, on: bool) -> None:
+        """`TAPCLIP_FLAG_KSPLIT`: K-split the tiles of partial GEMM rounds over idle CUs (on: the launch finishes sooner --
+        a tower that has the GPU to itself; off: fewest CU-seconds -- a tower that shares it with another stream)."""
+        self._check(self.lib.tapclip_tower_set_flag(self.handle, _lib.FLAG_KSPLIT, int(bool(on))))
+
     # -- weights -----------------------------------------------------------------------------
     def _wanted(self, key: str) -> Optional[str]:
         raise NotImplementedError

@@ -117,6 +117,32 @@ class FullModel(nn.Module):
             module._clip_version = v
             module.prompt_learner.refresh_token_bank()
 
+    # ---- scheduling of the towers' GEMMs ---------------------------------------------------------
+    class _ForwardGemms:
+        """Context of every FORWARD pass FullModel drives: both towers launch their GEMMs without the K-split of partial
+        rounds (`TAPCLIP_FLAG_KSPLIT` 0).  The split buys latency with CU-time -- right for a tower alone on the GPU, wrong
+        while the other tower's stream can use the idle CUs: the overlapped forward of BASELINE configs[2] is 12.7 ms with
+        the splits and 12.2 ms without (tools/train_phases.py, same box, interleaved).  The serial order
+        (`overlap_towers=False`) runs under the same setting, so the two orders stay bit-identical; the backward runs
+        after the context, split again (the text tower then has the GPU to itself)."""
+
+        def __init__(self, clip):
+            self.clip = clip
+
+        def __enter__(self):
+            depth = getattr(self.clip, "_forward_gemms_depth", 0)
+            self.clip._forward_gemms_depth = depth + 1
+            if depth == 0:
+                for t in (self.clip._vision, self.clip._text):
+                    t.set_ksplit(False)
+
+        def __exit__(self, *exc):
+            self.clip._forward_gemms_depth -= 1
+            if self.clip._forward_gemms_depth == 0:  # (the towers may have been re-packed meanwhile: address them anew)
+                for t in (self.clip._vision, self.clip._text):
+                    t.set_ksplit(True)
+            return False
+
     # ---- image side ----------------------------------------------------------------------------
     def _image_features_begin(self, images: torch.Tensor):
         """Launch `encode_image` (reference model_wrapper.py:40-41); returns (features, stream to join)."""
@@ -158,6 +184,10 @@ class FullModel(nn.Module):
         return self._text_features_uncached()
 
     def _text_features_uncached(self) -> torch.Tensor:
+        with FullModel._ForwardGemms(self.clip):  # (re-entrant: forward() is already inside one)
+            return self._text_features_passes()
+
+    def _text_features_passes(self) -> torch.Tensor:
         pl, clip = self.prompt_learner, self.clip
         P = pl.prompt_len
         ctx, tok = pl.stacked_context().detach(), pl.stacked_tokens()
@@ -212,18 +242,19 @@ class FullModel(nn.Module):
         trainable PromptAdjustor net) and `logit_scale`; the attention capture is a constant, as the
         reference's hook detaches it (clip_wrapper.py:36)."""
         pl, clip = self.prompt_learner, self.clip
-        with torch.no_grad():
-            image_feat, side = self._image_features_begin(images)
-            ctx_c, tok = pl.stacked_context().detach(), pl.stacked_tokens()
-            clip.reset()
-            clip.model.transformer.capture(engine.build_prompts(ctx_c, tok))
-            attn_map = clip.get_attention_map()
-            if attn_map.dim() == 2:
-                attn_map = attn_map.unsqueeze(1)
-            attribution = self.attribution_monitor(attn_map)
-        ctx = pl.stacked_context()                                   # differentiable w.r.t. every context_bank entry
-        adjusted = torch.cat([self.prompt_adjustor(ctx, attribution), tok], dim=1)
-        text_feat = _TextTowerFn.apply(adjusted, clip)
+        with FullModel._ForwardGemms(clip):  # (the backward, later, runs with the K-split on again)
+            with torch.no_grad():
+                image_feat, side = self._image_features_begin(images)
+                ctx_c, tok = pl.stacked_context().detach(), pl.stacked_tokens()
+                clip.reset()
+                clip.model.transformer.capture(engine.build_prompts(ctx_c, tok))
+                attn_map = clip.get_attention_map()
+                if attn_map.dim() == 2:
+                    attn_map = attn_map.unsqueeze(1)
+                attribution = self.attribution_monitor(attn_map)
+            ctx = pl.stacked_context()                                   # differentiable w.r.t. every context_bank entry
+            adjusted = torch.cat([self.prompt_adjustor(ctx, attribution), tok], dim=1)
+            text_feat = _TextTowerFn.apply(adjusted, clip)
         with torch.no_grad():
             image_feat = self._image_features_end(image_feat, side)
             image_feat, labels = self._gather(image_feat, labels)
@@ -265,8 +296,9 @@ class FullModel(nn.Module):
                 logits = self._forward_literal(images)
                 labels = None if labels is None else labels.to(logits.device)
             else:
-                image_feat, side = self._image_features_begin(images)                     # model_wrapper.py:40-41
-                text_feat = self.text_features()
+                with FullModel._ForwardGemms(self.clip):
+                    image_feat, side = self._image_features_begin(images)                 # model_wrapper.py:40-41
+                    text_feat = self.text_features()
                 image_feat = self._image_features_end(image_feat, side)
                 image_feat, labels = self._gather(image_feat, labels)
                 logits = engine.logits(image_feat, text_feat, float(self.logit_scale.exp()))  # :79,83
