@@ -118,6 +118,7 @@ for h, kind in handles:
     assert rc in (_lib.EINVAL, _lib.ESTATE), rc
     assert lib.tapclip_profile_enable(h, 1) == 0 and lib.tapclip_profile_enable(None, 1) == _lib.EINVAL
     assert lib.tapclip_tower_set_flag(h, _lib.FLAG_PRUNE_LAST_BLOCK, 0) == 0 and lib.tapclip_tower_set_flag(h, _lib.FLAG_PRUNE_LAST_BLOCK, 1) == 0
+    assert lib.tapclip_tower_set_flag(h, _lib.FLAG_KSPLIT, 0) == 0 and lib.tapclip_tower_set_flag(h, _lib.FLAG_KSPLIT, 1) == 0
     assert lib.tapclip_tower_set_flag(h, 99, 1) == _lib.EINVAL and "unknown tower flag" in err()
     assert lib.tapclip_tower_set_flag(None, _lib.FLAG_PRUNE_LAST_BLOCK, 1) == _lib.EINVAL
     ms, n = (C.c_float * len(_lib.PROFILE_SLOTS))(), (C.c_int64 * len(_lib.PROFILE_SLOTS))()

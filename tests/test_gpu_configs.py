@@ -13,6 +13,7 @@ REFERENCE's own classes (oracle/make_golden.py):
 
 Tolerances as in test_gpu_parity.py: TOL = 1e-3 for the modes that claim BASELINE.json's bound (bf16x3, and fp16 =
 IEEE-half image tower + split-bf16 text tower), TOL_BF16 = 2e-2 for plain bf16 (reported, not the parity claim)."""
+import contextlib
 import math
 import os
 import re
@@ -497,6 +498,41 @@ def test_vit_l14_336_batch_128_properties(eng):
         tower.close()
         del tower
         torch.cuda.empty_cache()
+
+
+def test_ksplit_flag_changes_summation_order_only_and_fullmodel_restores_it(eng):
+    """`TAPCLIP_FLAG_KSPLIT` (include/tapclip.h): 1 K-splits the tiles of partial GEMM rounds over idle CUs, 0 does not.
+    ViT-B/16 at batch 256 (BASELINE configs[1]): c_proj's 79 tail tiles are the only ones the image tower splits, so the
+    two settings agree bit for bit on the rows of the whole rounds and to the bf16 mode's rounding on the rest; each
+    setting is run-to-run bit-identical.  FullModel clears the flag for its forward passes (both towers in flight:
+    CU-time, not latency -- reference models/model_wrapper.py:40-75) and must leave both towers with it set again."""
+    from tap_clip_amd.models import CLIPWrapper, FullModel
+    from test_gpu_parity import TOL_TAIL_SPLIT
+
+    cfg = configs.get_config("ViT-B-16")
+    sd = synth.make_state_dict(cfg, seed=2)
+    clip = CLIPWrapper("ViT-B-16", None, DEV, precision="bf16", attn_semantics="intended", state_dict=sd)
+    tower = clip._vision
+    tower.set_prune_last_block(False)
+    images = synth.make_images(256, cfg, 0).to(DEV)
+    on = tower.encode_image(images, normalize=True).clone()
+    tower.set_ksplit(False)
+    off = tower.encode_image(images, normalize=True).clone()
+    assert torch.equal(off, tower.encode_image(images, normalize=True))
+    tower.set_ksplit(True)
+    assert torch.equal(on, tower.encode_image(images, normalize=True))
+    assert torch.equal(on[:128], off[:128]), "rows of the whole rounds must not depend on the flag"
+    assert not torch.equal(on, off) and rel_l2(off.cpu(), on.cpu()) < TOL_TAIL_SPLIT
+    with contextlib.redirect_stdout(sys.stderr):
+        model = FullModel([f"class_{i}" for i in range(65)], clip, prompt_len=16, class_specific=True).eval()
+    with torch.no_grad():
+        a = model(images)["logits"].clone()
+        assert torch.equal(a, model(images)["logits"])
+    assert torch.equal(on, tower.encode_image(images, normalize=True)), "FullModel must hand the towers back with the K-split on"
+    model.train()
+    out = model(images, synth.make_labels(256, 65).to(DEV))
+    out["loss"].backward()
+    assert torch.equal(on, tower.encode_image(images, normalize=True))
 
 
 @pytest.mark.parametrize("name,batch", [("ViT-B-16", 64), ("ViT-B-32", 8), ("ViT-L-14-336", 3), ("tiny", 1100)])
