@@ -141,6 +141,41 @@ int tapclip_text_backward_saved(tapclip_tower_t* tower, const void* saved, size_
                                 float* grad_x, void* workspace, size_t workspace_bytes,
                                 tapclip_stream_t stream);
 
+/* ---- tied padding rows.  FullModel builds every text sequence as [P context rows | token_embedding(tokenizer(text))]
+ * (reference models/prompt_learner.py:31-34,62-65) and runs the transformer on it without positional embedding and
+ * without mask (reference models/model_wrapper.py:58,72).  A tokenised prompt is zero-padded to 77 ids, so the trailing
+ * rows of every sequence are ONE embedding row repeated (68-70 of 93 rows at BASELINE.json configs[2]); identical rows
+ * stay identical through every block, and the whole pass is the same function of the DISTINCT rows when the attention
+ * counts the repeated key `tail_run` times.  The *_tied entry points run exactly that: Tc = tokens - tail_run + 1 rows
+ * per sequence inside, full [n, tokens, ...] tensors outside, results equal to the untied calls to fp32 round-off (split
+ * modes) / to the mode's own rounding (16-bit modes).  tail_run = 1 is the untied computation.  No causal mask (a
+ * position-free notion); attention write-back / backward limits apply to Tc.
+ *   tapclip_text_tail_run        largest r such that the last r rows of EVERY sequence of x [n, tokens, width] are
+ *                                bit-identical (>= 1); synchronous (waits for `stream`) -- call it once per token bank.
+ *   tapclip_text_forward_tied    as tapclip_text_forward (causal = 0): rows / columns of the outputs that belong to the
+ *                                run are filled in (each tied column gets 1/tail_run of the group's probability).
+ *   tapclip_text_forward_saved_tied / tapclip_text_backward_saved_tied   the training pair; `saved` needs
+ *                                tapclip_text_saved_bytes(tower, n_seq, tokens - tail_run + 1).  The tied rows are ONE
+ *                                variable: the backward sums grad_hidden over the run on entry and returns the group's
+ *                                input gradient in the run's FIRST row (zeros in the others); rows before the run (the
+ *                                context rows FullModel differentiates) get exactly the untied gradients.
+ * The claim "the last tail_run rows are identical" is checked on the device, without a host round trip: if it is false
+ * the handle is poisoned -- every output of every later *_tied call on it is NaN -- until tapclip_text_tied_violations
+ * (synchronous) has reported and cleared the condition. */
+int tapclip_text_tail_run(const float* x, int32_t n_seq, int32_t tokens, int32_t width, int32_t* run_out,
+                          tapclip_stream_t stream);
+size_t tapclip_text_tied_workspace_bytes(const tapclip_tower_t* text, int64_t n_seq, int32_t tokens, int32_t tail_run);
+int tapclip_text_forward_tied(tapclip_tower_t* text, const float* x, int32_t n_seq, int32_t tokens, int32_t tail_run,
+                              float* out_hidden, float* attn_heads, float* attn_mean, float* attn_out,
+                              void* workspace, size_t workspace_bytes, tapclip_stream_t stream);
+int tapclip_text_forward_saved_tied(tapclip_tower_t* text, const float* x, int32_t n_seq, int32_t tokens,
+                                    int32_t tail_run, float* out_hidden, void* saved, size_t saved_bytes,
+                                    void* workspace, size_t workspace_bytes, tapclip_stream_t stream);
+int tapclip_text_backward_saved_tied(tapclip_tower_t* text, const void* saved, size_t saved_bytes,
+                                     const float* grad_hidden, int32_t n_seq, int32_t tokens, int32_t tail_run,
+                                     float* grad_x, void* workspace, size_t workspace_bytes, tapclip_stream_t stream);
+int tapclip_text_tied_violations(tapclip_tower_t* text, int32_t* violated_out, tapclip_stream_t stream);
+
 /* ---- prompt-tuning backward (reference train.py:99-105: `loss.backward()`; only
  * `prompt_learner.context_bank.*` and `logit_scale` receive gradients, every CLIP weight is frozen,
  * clip_wrapper.py:19-20, so these are dX-only).  Stateless: tapclip_text_backward recomputes the forward
@@ -265,6 +300,8 @@ void tapclip_comm_destroy(tapclip_comm_t* comm);
  * settings by fp32 summation order only (the rounding-level dependence documented for the tail split). */
 #define TAPCLIP_FLAG_KSPLIT 2
 int tapclip_tower_set_flag(tapclip_tower_t* tower, int32_t flag, int32_t value);
+/* the current value of a flag (a caller that changes one for a while restores what it found, not the default) */
+int tapclip_tower_get_flag(const tapclip_tower_t* tower, int32_t flag, int32_t* value);
 
 /* ---- per-stage timing (HIP events on `stream`) for bench.py's roofline object.
  * When enabled, tapclip_encode_image records events around each kernel family;

@@ -37,6 +37,12 @@ SYMBOLS = [
     ("tapclip_text_saved_bytes", _sz, [_p, _i64, _i32]),
     ("tapclip_text_forward_saved", _i32, [_p, _p, _i32, _i32, _i32, _p, _p, _sz, _p, _sz, _p]),
     ("tapclip_text_backward_saved", _i32, [_p, _p, _sz, _p, _i32, _i32, _i32, _p, _p, _sz, _p]),
+    ("tapclip_text_tail_run", _i32, [_p, _i32, _i32, _i32, C.POINTER(_i32), _p]),
+    ("tapclip_text_tied_workspace_bytes", _sz, [_p, _i64, _i32, _i32]),
+    ("tapclip_text_forward_tied", _i32, [_p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
+    ("tapclip_text_forward_saved_tied", _i32, [_p, _p, _i32, _i32, _i32, _p, _p, _sz, _p, _sz, _p]),
+    ("tapclip_text_backward_saved_tied", _i32, [_p, _p, _sz, _p, _i32, _i32, _i32, _p, _p, _sz, _p]),
+    ("tapclip_text_tied_violations", _i32, [_p, C.POINTER(_i32), _p]),
     ("tapclip_text_pool_project_backward", _i32, [_p, _p, _i32, _i32, _i32, _p, _p, _p]),
     ("tapclip_logits_backward", _i32, [_p, _p, _p, _f32, _i32, _i32, _i32, _p, _p, _p]),
     ("tapclip_embed_tokens", _i32, [_p, _p, _i32, _i32, _i32, _p, _p]),
@@ -54,6 +60,7 @@ SYMBOLS = [
     ("tapclip_allgather", _i32, [_p, _p, _p, _sz, _p]),
     ("tapclip_comm_destroy", None, [_p]),
     ("tapclip_tower_set_flag", _i32, [_p, _i32, _i32]),
+    ("tapclip_tower_get_flag", _i32, [_p, _i32, C.POINTER(_i32)]),
     ("tapclip_profile_enable", _i32, [_p, _i32]),
     ("tapclip_profile_read", _i32, [_p, C.POINTER(_f32), C.POINTER(_i64)]),
     ("tapclip_last_error", C.c_char_p, []),

@@ -236,6 +236,12 @@ __global__ __launch_bounds__(512, (NKT % 2) ? 6 : 1) void attn_kernel(AttnArgs a
           if (key >= T || (a.causal && key > qi)) sc[kt][e] = -INFINITY;
         }
       }
+      // tied padding (tied.hip): the last key stands for m identical rows -- exp(s + ln m) = m exp(s)
+      if (a.last_key_bias != 0.f && kt == ((T - 1) >> 4)) {  // kernel-uniform
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (4 * g + e == ((T - 1) & 15)) sc[kt][e] += a.last_key_bias;
+      }
       mx = fmaxf(mx, fmaxf(fmaxf(sc[kt][0], sc[kt][1]), fmaxf(sc[kt][2], sc[kt][3])));
     }
     mx = rows_max(mx);
@@ -749,7 +755,8 @@ hipError_t launch_attention_pooled(const bf16_t* q_hi, const bf16_t* q_lo, const
 hipError_t launch_attention(const AttnArgs& a, bool split, hipStream_t s) {
   if (a.T <= 0 || a.D != a.H * 64 || a.n_seq <= 0) return hipErrorInvalidValue;
   static const bool force_flash = getenv("TAPCLIP_ATTN_FORCE_FLASH") != nullptr;  // tools/gemm_bench: compare the two kernels
-  if (a.T > 256 || (force_flash && a.probs == nullptr)) {  // whole-head-in-LDS kernel holds at most 256 keys: flash-style kernel (no probability write-back)
+  if (a.last_key_bias != 0.f && (a.T > 256 || a.causal)) return hipErrorInvalidValue;  // (a tied key has no position: no mask; the flash kernel does not know it)
+  if (a.T > 256 || (force_flash && a.probs == nullptr && a.last_key_bias == 0.f)) {  // whole-head-in-LDS kernel holds at most 256 keys: flash-style kernel (no probability write-back)
     if (a.probs != nullptr) return hipErrorInvalidValue;
     return split ? launch_flash<true>(a, s) : launch_flash<false>(a, s);
   }

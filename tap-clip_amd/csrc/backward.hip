@@ -194,6 +194,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs a) {
       const int i = ti * 16 + 4 * lq + e, j = tj * 16 + lr;
       float sv = acc[e];
       if (j >= T || (a.causal && j > i)) sv = -INFINITY;
+      if (j == T - 1) sv += a.last_key_bias;  // tied padding (tied.hip): the forward counted the last key m times, ln m here
       P[i * LP + j] = sv;
     }
   }

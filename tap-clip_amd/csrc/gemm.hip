@@ -236,7 +236,7 @@ bool gemm256_supports(const GemmArgs& a);
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, bool split, hipStream_t s) {
   if (a.M <= 0 || a.N % BN != 0 || a.K % BK != 0 || a.K <= 0) return hipErrorInvalidValue;
   if ((a.lda % 8) != 0 || (a.ldo % 4) != 0) return hipErrorInvalidValue;
-  // M >= 2048 (the image tower: M = 50 432; the 65-class text pass: M = 6 045): the persistent 256-row kernel
+  // Large M (the image tower: M = 50 432; the 65-class text pass on every row: M = 6 045): the persistent 256-row kernel
   // of gemm256.hip.  The register-staged kernel in this file is latency-bound at K = 512 (57 us per text
   // GEMM against ~15 us) and keeps only the small problems: few classes, unit tests, tiny models.
   // TAPCLIP_GEMM_TILE=128|256 pins the choice (tests exercise both kernels on the same problem)
@@ -244,7 +244,16 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, bool split, hipStream_t 
     const char* e = getenv("TAPCLIP_GEMM_TILE");
     return e ? atoi(e) : 0;
   }();
-  if (gemm256_supports(a) && (forced == 256 || (forced != 128 && a.M >= 2048))) return launch_gemm256(a, epilogue, split, s);
+  // Round 4: with the tied padding rows merged the 65-class text pass is M = 65 x 24..26 = 1 560..1 690 rows.  Measured at
+  // M = 1 560 (tools/train_phases.py, text_features alone): bf16 2.30 ms on the persistent kernel against 4.53 ms on the
+  // register-staged one; split-bf16 5.79 against 4.92 ms (there the persistent kernel K-splits every tile and pays a fix-up
+  // per GEMM) -- hence 1 024 rows for one product, 2 048 for three.  TAPCLIP_GEMM256_MIN_M overrides both (experiments).
+  static const int64_t min_m_env = [] {
+    const char* e = getenv("TAPCLIP_GEMM256_MIN_M");
+    return e ? (int64_t)atoll(e) : (int64_t)0;
+  }();
+  const int64_t min_m = min_m_env > 0 ? min_m_env : (split ? 2048 : 1024);
+  if (gemm256_supports(a) && (forced == 256 || (forced != 128 && a.M >= min_m))) return launch_gemm256(a, epilogue, split, s);
 #define TAPCLIP_GEMM_CASE(E)                                      \
   case E:                                                         \
     return split ? launch_t<E, true>(a, s) : launch_t<E, false>(a, s);

@@ -122,6 +122,9 @@ struct AttnArgs {
   float* probs;          // nullable [n, H, T, T] fp32 softmax probabilities
   int32_t n_seq, T, H, D;
   int32_t causal;
+  // tied padding (tied.hip): ln(m) added to the score of the LAST key of every sequence, i.e. that key counts m times in
+  // every softmax (0 = an ordinary key).  Not with causal, not in the flash kernel (T > 256).
+  float last_key_bias = 0.f;
   // fp8 path: when out_q is set the output leaves as MXFP8 (e4m3 [n*T, D] + scales [D/64][out_m_pad][2]; a head's
   // 64 columns are one k-step of the out_proj GEMM) instead of bf16
   uint8_t* out_q = nullptr;
@@ -169,6 +172,7 @@ struct AttnBwdArgs {
   bf16_t* dqkv_hi;        // [n*T, 3D]
   bf16_t* dqkv_lo;
   int32_t n_seq, T, H, D, causal;
+  float last_key_bias = 0.f;  // as AttnArgs.last_key_bias: the forward's softmax is recomputed with it
 };
 size_t attn_bwd_lds_bytes(int T);
 hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s);
@@ -181,6 +185,17 @@ hipError_t launch_logits_bwd(const float* dl, const float* logits, const float* 
                              int32_t E, float* d_txt, float* d_logscale, hipStream_t s);
 hipError_t launch_pack_transpose(const float* src, int64_t N, int32_t K, int64_t scale_rows, float scale, bf16_t* hi,
                                  bf16_t* lo, hipStream_t s);
+
+// ---- tied padding rows (tied.hip): the last `run` rows of every sequence of x [n, T, D] are one row repeated.
+// Tc = T - run + 1 below; `flag` is a device int the kernels raise when a row of the run differs (bitwise) from the others,
+// and every expand kernel writes NaN instead of results while it is raised.
+hipError_t launch_tail_run(const float* x, int32_t n, int32_t T, int32_t D, int32_t* run_min_dev, hipStream_t s);  // *run_min_dev = min over sequences (preset to T by the caller)
+hipError_t launch_tied_compact(const float* x, int32_t n, int32_t T, int32_t Tc, int32_t D, float* xc, int* flag, hipStream_t s);
+hipError_t launch_tied_sum_tail(const float* g, int32_t n, int32_t T, int32_t Tc, int32_t D, float* gc, hipStream_t s);
+hipError_t launch_tied_expand_rows(const float* hc, int32_t n, int32_t T, int32_t Tc, int32_t D, int32_t zero_tail, float* h, const int* flag, hipStream_t s);
+// pc [nb, Hm, Tc, Tc] -> out [nb, T, T]: mean over Hm, rows / columns >= Tc - 1 replicate the last compact row / column, the
+// replicated columns divided by run
+hipError_t launch_tied_expand_map(const float* pc, int32_t nb, int32_t Hm, int32_t T, int32_t Tc, float* out, const int* flag, hipStream_t s);
 
 hipError_t launch_embed_tokens(const float* table, int32_t vocab, const float* pos, const int64_t* tokens,
                                int32_t n, int32_t L, int32_t D, int32_t add_pos, float* out, int* bad_flag, hipStream_t s);

@@ -95,6 +95,7 @@ struct tapclip_tower {
   // text
   float *tok_emb = nullptr, *lnfin_g = nullptr, *lnfin_b = nullptr, *text_proj = nullptr;
   int* bad_token = nullptr;   // device flag of tapclip_embed_tokens: set when a token id is outside the table
+  int* tied_flag = nullptr;   // device flag of the tied-padding entry points (tied.hip): raised when the claimed run of identical rows is not one
   float* split_ws = nullptr;  // scratch for the K-split tail tiles of gemm256.hip (64 MiB, handle-owned)
   // profiling
   bool prof_on = false;
@@ -452,7 +453,7 @@ int run_last_block_pooled(tapclip_tower* t, float* x, int64_t n_seq, int tokens,
 
 int run_blocks(tapclip_tower* t, float* x, int64_t n_seq, int tokens, int causal, const Workspace& w,
                float* probs_last, float* attn_out_last, hipStream_t s, bool capture_only = false, float* pooled_out = nullptr,
-               bf16_t** pooled_d_hi = nullptr, bf16_t** pooled_d_lo = nullptr) {
+               bf16_t** pooled_d_hi = nullptr, bf16_t** pooled_d_lo = nullptr, float last_key_bias = 0.f) {
   const bool x24 = t->x24 && t->cfg.kind == TAPCLIP_TOWER_VISION;  // residual stream in w.x24_hi / w.x24_lo instead of x
   // image tower, 16-bit modes: the fp32 residual rows are streamed past the caches (layernorm.hip NTX)
   static const bool no_ntx = getenv("TAPCLIP_NO_STREAM_X") != nullptr;
@@ -487,6 +488,7 @@ int run_blocks(tapclip_tower* t, float* x, int64_t n_seq, int tokens, int causal
       a.out_hi = w.ao_hi; a.out_lo = w.ao_lo;
       a.probs = last ? probs_last : nullptr;
       a.n_seq = (int)n_seq; a.T = tokens; a.H = H; a.D = D; a.causal = causal;
+      a.last_key_bias = last_key_bias;
       ProfScope ps(t, 3, s);
       HIP_TRY(launch_attention(a, t->split, s));
       DBG_SYNC(4, s);
@@ -634,10 +636,11 @@ Saved carve_saved(const tapclip_tower* t, int64_t M, void* base) {
 // x1[l] = x0[l] + attention branch, x0[l+1] = x1[l] + MLP branch); 25 device copies of [M, D] fp32 per call are gone.
 // On return *x_last = x1[L-1]: x without the last c_proj branch, which is pending in w.d.
 int run_forward_saving(tapclip_tower* t, const float* x_in, int64_t n_seq, int tokens, int causal, const Workspace& w,
-                       const Saved& sv, hipStream_t s, const float** x_last) {
+                       const Saved& sv, hipStream_t s, const float** x_last, float last_key_bias = 0.f) {
   const int64_t M = n_seq * tokens;
   const int D = t->cfg.width, F = t->cfg.mlp_dim, H = t->cfg.heads, L = t->cfg.layers;
-  HIP_TRY(hipMemcpyAsync(sv.x0[0], x_in, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
+  // (x_in == nullptr: the caller has written the input rows into sv.x0[0] itself -- the tied-padding entry point compacts into it)
+  if (x_in != nullptr) HIP_TRY(hipMemcpyAsync(sv.x0[0], x_in, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
   int rc;
   for (int li = 0; li < L; ++li) {
     const LayerW& Lw = t->layers[li];
@@ -649,6 +652,7 @@ int run_forward_saving(tapclip_tower* t, const float* x_in, int64_t n_seq, int t
     a.out_hi = sv.ao_hi[li]; a.out_lo = sv.ao_lo[li];
     a.probs = nullptr;
     a.n_seq = (int)n_seq; a.T = tokens; a.H = H; a.D = D; a.causal = causal;
+    a.last_key_bias = last_key_bias;
     HIP_TRY(launch_attention(a, t->split, s));
     if ((rc = gemm(t, 4, EPI_BIAS_BF16, sv.ao_hi[li], sv.ao_lo[li], D, Lw.wo, Lw.bo, M, D, D, w.d_hi, w.d_lo, nullptr, D, s))) return rc;
     HIP_TRY(launch_add_layernorm(sv.x0[li], w.d_hi, w.d_lo, Lw.ln2_g, Lw.ln2_b, M, D, w.xn_hi, w.xn_lo, s, sv.x1[li]));
@@ -663,7 +667,7 @@ int run_forward_saving(tapclip_tower* t, const float* x_in, int64_t n_seq, int t
 // dL/d(x_in).  Scratch re-uses the forward workspace: g = w.d (branch gradient as a GEMM operand),
 // w.h = dL/dh then dL/dz, w.ao = dL/d(attention out), w.qkv = dL/d(qkv), w.x = fp32 dL/d(LN output)
 int run_backward_sweep(tapclip_tower* t, float* dx, int64_t n_seq, int tokens, int causal, const Workspace& w,
-                       const Saved& sv, hipStream_t s) {
+                       const Saved& sv, hipStream_t s, float last_key_bias = 0.f) {
   const int64_t M = n_seq * tokens;
   const int D = t->cfg.width, F = t->cfg.mlp_dim, H = t->cfg.heads, L = t->cfg.layers;
   int rc;
@@ -687,6 +691,7 @@ int run_backward_sweep(tapclip_tower* t, float* dx, int64_t n_seq, int tokens, i
     b.dout_hi = w.ao_hi; b.dout_lo = w.ao_lo;
     b.dqkv_hi = w.qkv_hi; b.dqkv_lo = w.qkv_lo;
     b.n_seq = (int)n_seq; b.T = tokens; b.H = H; b.D = D; b.causal = causal;
+    b.last_key_bias = last_key_bias;
     HIP_TRY(launch_attention_bwd(b, s));
     if ((rc = gemm(t, 2, EPI_BIAS_F32, w.qkv_hi, w.qkv_lo, 3 * D, Lw.wqkv_t, nullptr, M, D, 3 * D, nullptr, nullptr, dn, D, s))) return rc;
     HIP_TRY(launch_ln_bwd(sv.x0[li], Lw.ln1_g, dn, M, D, dx, li > 0 ? w.d_hi : nullptr, li > 0 ? w.d_lo : nullptr, s));
@@ -1051,6 +1056,147 @@ int tapclip_text_backward_saved(tapclip_tower_t* t, const void* saved, size_t sa
   return run_backward_sweep(t, grad_x, n_seq, tokens, causal, w, sv, s);
 }
 
+// ---- tied padding rows (tied.hip): the same three text entry points on the DISTINCT rows of every sequence.
+namespace {
+struct Tied {
+  int Tc = 0;         // rows per sequence the tower runs on: tokens - tail_run + 1
+  float bias = 0.f;   // ln(tail_run): the last compact key counts tail_run times in every softmax
+  Workspace w;
+  float* extra = nullptr;  // fp32 [n * Tc, D] behind the carved workspace
+  size_t bytes = 0;
+};
+Tied carve_tied(const tapclip_tower* t, int64_t n_seq, int tokens, int tail_run, void* base) {
+  Tied td;
+  td.Tc = tokens - tail_run + 1;
+  td.bias = logf((float)tail_run);
+  td.w = carve(t, n_seq, td.Tc, base);
+  const size_t off = align_up(td.w.bytes);
+  td.extra = base ? reinterpret_cast<float*>(static_cast<char*>(base) + off) : nullptr;
+  td.bytes = off + align_up((size_t)n_seq * td.Tc * t->cfg.width * 4);
+  return td;
+}
+int tied_begin(tapclip_tower* t, int n_seq, int tokens, int tail_run, hipStream_t s) {
+  if (t->cfg.kind != TAPCLIP_TOWER_TEXT) return fail(TAPCLIP_EINVAL, "the tied-padding entry points need a text tower");
+  if (n_seq <= 0 || tokens <= 0) return fail(TAPCLIP_EINVAL, "bad n_seq/tokens (%d, %d)", n_seq, tokens);
+  if (tail_run < 1 || tail_run > tokens) return fail(TAPCLIP_EINVAL, "tail_run %d outside [1, tokens = %d]", tail_run, tokens);
+  int rc = check_ready(t);
+  if (rc) return rc;
+  if (!t->tied_flag) {
+    void* p = nullptr;
+    if ((rc = dev_alloc(t, sizeof(int), &p))) return rc;
+    t->tied_flag = static_cast<int*>(p);
+    HIP_TRY(hipMemsetAsync(t->tied_flag, 0, sizeof(int), s));  // (sticky afterwards: see tapclip_text_tied_violations)
+  }
+  return TAPCLIP_OK;
+}
+}  // namespace
+
+int tapclip_text_tail_run(const float* x, int32_t n_seq, int32_t tokens, int32_t width, int32_t* run_out, tapclip_stream_t stream) {
+  if (!x || !run_out) return fail(TAPCLIP_EINVAL, "null argument");
+  if (n_seq <= 0 || tokens <= 0 || width <= 0) return fail(TAPCLIP_EINVAL, "bad n_seq/tokens/width (%d, %d, %d)", n_seq, tokens, width);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int* dev = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), sizeof(int)));
+  int run = tokens;
+  hipError_t e = hipMemcpyAsync(dev, &run, sizeof(int), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = launch_tail_run(x, n_seq, tokens, width, dev, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(&run, dev, sizeof(int), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);  // off the hot path: once per token bank
+  (void)hipFree(dev);
+  if (e != hipSuccess) return fail(TAPCLIP_EHIP, "tapclip_text_tail_run failed: %s", hipGetErrorString(e));
+  *run_out = run;
+  return TAPCLIP_OK;
+}
+
+size_t tapclip_text_tied_workspace_bytes(const tapclip_tower_t* t, int64_t n_seq, int32_t tokens, int32_t tail_run) {
+  if (!t || n_seq <= 0 || tokens <= 0 || tail_run < 1 || tail_run > tokens || t->cfg.kind != TAPCLIP_TOWER_TEXT) return 0;
+  return carve_tied(t, n_seq, tokens, tail_run, nullptr).bytes;
+}
+
+int tapclip_text_tied_violations(tapclip_tower_t* t, int32_t* out, tapclip_stream_t stream) {
+  if (!t || !out) return fail(TAPCLIP_EINVAL, "null argument");
+  *out = 0;
+  if (!t->tied_flag) return TAPCLIP_OK;  // no tied call yet
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int v = 0;
+  HIP_TRY(hipMemcpyAsync(&v, t->tied_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemsetAsync(t->tied_flag, 0, sizeof(int), s));  // read and clear
+  HIP_TRY(hipStreamSynchronize(s));
+  *out = v;
+  return TAPCLIP_OK;
+}
+
+int tapclip_text_forward_tied(tapclip_tower_t* t, const float* x_in, int32_t n_seq, int32_t tokens, int32_t tail_run, float* out_hidden,
+                              float* attn_heads, float* attn_mean, float* attn_out, void* workspace, size_t workspace_bytes,
+                              tapclip_stream_t stream) {
+  if (!t || !x_in || !workspace) return fail(TAPCLIP_EINVAL, "null argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = tied_begin(t, n_seq, tokens, tail_run, s);
+  if (rc) return rc;
+  const int D = t->cfg.width, H = t->cfg.heads;
+  const Tied td = carve_tied(t, n_seq, tokens, tail_run, workspace);
+  if (td.Tc > 256 && (attn_heads || attn_mean)) return fail(TAPCLIP_EINVAL, "attention write-back needs at most 256 distinct tokens (got %d)", td.Tc);
+  if (td.bytes > workspace_bytes) return fail(TAPCLIP_EWORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, td.bytes);
+  const Workspace& w = td.w;
+  HIP_TRY(launch_tied_compact(x_in, n_seq, tokens, td.Tc, D, w.x, t->tied_flag, s));
+  float* probs = (attn_heads || attn_mean) ? w.probs : nullptr;
+  rc = run_blocks(t, w.x, n_seq, td.Tc, 0, w, probs, attn_out ? td.extra : nullptr, s, /*capture_only=*/out_hidden == nullptr, nullptr, nullptr,
+                  nullptr, td.bias);
+  if (rc) return rc;
+  if (out_hidden) {
+    HIP_TRY(launch_add_delta(w.x, w.d_hi, w.d_lo, (int64_t)n_seq * td.Tc * D, s));  // last pending branch
+    HIP_TRY(launch_tied_expand_rows(w.x, n_seq, tokens, td.Tc, D, 0, out_hidden, t->tied_flag, s));
+  }
+  if (attn_heads) HIP_TRY(launch_tied_expand_map(probs, n_seq * H, 1, tokens, td.Tc, attn_heads, t->tied_flag, s));
+  if (attn_mean) HIP_TRY(launch_tied_expand_map(probs, n_seq, H, tokens, td.Tc, attn_mean, t->tied_flag, s));
+  if (attn_out) HIP_TRY(launch_tied_expand_rows(td.extra, n_seq, tokens, td.Tc, D, 0, attn_out, t->tied_flag, s));
+  return TAPCLIP_OK;
+}
+
+int tapclip_text_forward_saved_tied(tapclip_tower_t* t, const float* x_in, int32_t n_seq, int32_t tokens, int32_t tail_run,
+                                    float* out_hidden, void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes,
+                                    tapclip_stream_t stream) {
+  if (!t || !x_in || !out_hidden || !saved || !workspace) return fail(TAPCLIP_EINVAL, "null argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = tied_begin(t, n_seq, tokens, tail_run, s);
+  if (rc) return rc;
+  const int D = t->cfg.width;
+  const Tied td = carve_tied(t, n_seq, tokens, tail_run, workspace);
+  if (td.bytes > workspace_bytes) return fail(TAPCLIP_EWORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, td.bytes);
+  const int64_t Mc = (int64_t)n_seq * td.Tc;
+  const Saved sv = carve_saved(t, Mc, saved);
+  if (sv.bytes > saved_bytes) return fail(TAPCLIP_EWORKSPACE, "saved buffer %zu B < required %zu B", saved_bytes, sv.bytes);
+  HIP_TRY(launch_tied_compact(x_in, n_seq, tokens, td.Tc, D, sv.x0[0], t->tied_flag, s));
+  const float* x_last = nullptr;
+  if ((rc = run_forward_saving(t, nullptr, n_seq, td.Tc, 0, td.w, sv, s, &x_last, td.bias))) return rc;
+  HIP_TRY(hipMemcpyAsync(td.extra, x_last, (size_t)Mc * D * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(launch_add_delta(td.extra, td.w.d_hi, td.w.d_lo, Mc * D, s));  // last pending branch
+  HIP_TRY(launch_tied_expand_rows(td.extra, n_seq, tokens, td.Tc, D, 0, out_hidden, t->tied_flag, s));
+  return TAPCLIP_OK;
+}
+
+int tapclip_text_backward_saved_tied(tapclip_tower_t* t, const void* saved, size_t saved_bytes, const float* grad_hidden, int32_t n_seq,
+                                     int32_t tokens, int32_t tail_run, float* grad_x, void* workspace, size_t workspace_bytes,
+                                     tapclip_stream_t stream) {
+  if (!t || !saved || !grad_hidden || !grad_x || !workspace) return fail(TAPCLIP_EINVAL, "null argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = tied_begin(t, n_seq, tokens, tail_run, s);
+  if (rc) return rc;
+  const int D = t->cfg.width;
+  const Tied td = carve_tied(t, n_seq, tokens, tail_run, workspace);
+  if (attn_bwd_lds_bytes(td.Tc) > 160 * 1024) return fail(TAPCLIP_EINVAL, "text backward supports at most 96 distinct tokens per sequence (got %d)", td.Tc);
+  if (td.bytes > workspace_bytes) return fail(TAPCLIP_EWORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, td.bytes);
+  const int64_t Mc = (int64_t)n_seq * td.Tc;
+  const Saved sv = carve_saved(t, Mc, const_cast<void*>(saved));
+  if (sv.bytes > saved_bytes) return fail(TAPCLIP_EWORKSPACE, "saved buffer %zu B < required %zu B", saved_bytes, sv.bytes);
+  // the tied rows are ONE variable: its output gradient is the sum over the rows it stands for, and its input gradient
+  // (the sum of the per-row gradients) is returned in the group's first row, zeros in the others
+  HIP_TRY(launch_tied_sum_tail(grad_hidden, n_seq, tokens, td.Tc, D, td.extra, s));
+  if ((rc = run_backward_sweep(t, td.extra, n_seq, td.Tc, 0, td.w, sv, s, td.bias))) return rc;
+  HIP_TRY(launch_tied_expand_rows(td.extra, n_seq, tokens, td.Tc, D, 1, grad_x, t->tied_flag, s));
+  return TAPCLIP_OK;
+}
+
 int tapclip_text_pool_project_backward(tapclip_tower_t* t, const float* hidden, int32_t n_seq, int32_t tokens, int32_t normalize,
                                        const float* grad_out, float* grad_hidden, tapclip_stream_t stream) {
   if (!t || !hidden || !grad_out || !grad_hidden) return fail(TAPCLIP_EINVAL, "null argument");
@@ -1310,6 +1456,15 @@ int tapclip_tower_set_flag(tapclip_tower_t* t, int32_t flag, int32_t value) {
   switch (flag) {
     case TAPCLIP_FLAG_PRUNE_LAST_BLOCK: t->prune_last = value != 0; return TAPCLIP_OK;
     case TAPCLIP_FLAG_KSPLIT: t->ksplit = value != 0; return TAPCLIP_OK;
+    default: return fail(TAPCLIP_EINVAL, "unknown tower flag %d", flag);
+  }
+}
+
+int tapclip_tower_get_flag(const tapclip_tower_t* t, int32_t flag, int32_t* value) {
+  if (!t || !value) return fail(TAPCLIP_EINVAL, "null argument");
+  switch (flag) {
+    case TAPCLIP_FLAG_PRUNE_LAST_BLOCK: *value = t->prune_last ? 1 : 0; return TAPCLIP_OK;
+    case TAPCLIP_FLAG_KSPLIT: *value = t->ksplit ? 1 : 0; return TAPCLIP_OK;
     default: return fail(TAPCLIP_EINVAL, "unknown tower flag %d", flag);
   }
 }

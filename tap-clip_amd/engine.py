@@ -57,6 +57,11 @@ class _Tower:
         a tower that has the GPU to itself; off: fewest CU-seconds -- a tower that shares it with another stream)."""
         self._check(self.lib.tapclip_tower_set_flag(self.handle, _lib.FLAG_KSPLIT, int(bool(on))))
 
+    def get_ksplit(self) -> bool:
+        v = C.c_int32(0)
+        self._check(self.lib.tapclip_tower_get_flag(self.handle, _lib.FLAG_KSPLIT, C.byref(v)))
+        return bool(v.value)
+
     # -- weights -----------------------------------------------------------------------------
     def _wanted(self, key: str) -> Optional[str]:
         raise NotImplementedError
@@ -75,8 +80,11 @@ class _Tower:
         self._check(self.lib.tapclip_tower_ready(self.handle))  # strict=True semantics
 
     # -- scratch -----------------------------------------------------------------------------
-    def workspace(self, n_seq: int, tokens: int) -> Tuple[torch.Tensor, int]:
-        need = int(self.lib.tapclip_tower_workspace_bytes(self.handle, n_seq, tokens))
+    def workspace(self, n_seq: int, tokens: int, tail_run: int = 1) -> Tuple[torch.Tensor, int]:
+        if tail_run > 1:
+            need = int(self.lib.tapclip_text_tied_workspace_bytes(self.handle, n_seq, tokens, tail_run))
+        else:
+            need = int(self.lib.tapclip_tower_workspace_bytes(self.handle, n_seq, tokens))
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
@@ -156,10 +164,38 @@ class TextTower(_Tower):
             return key
         return None
 
+    @staticmethod
+    def _check_tail_run(tail_run: int, T: int, causal: bool) -> int:
+        tail_run = int(tail_run)
+        if tail_run < 1 or tail_run > T:
+            raise ValueError(f"tail_run must be in [1, {T}], got {tail_run}")
+        if tail_run > 1 and causal:
+            raise ValueError("tail_run > 1 (tied padding rows) has no meaning under the causal mask")
+        return tail_run
+
+    def tail_run(self, x: torch.Tensor) -> int:
+        """Largest r such that the last r rows of EVERY sequence of x [n,T,D] are bit-identical (>= 1): the run of tied
+        padding rows that `forward(..., tail_run=r)` may merge.  Synchronous -- once per token bank, not per step."""
+        xin = _dev_f32(x, self.device)
+        n, T, D = xin.shape
+        r = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.tapclip_text_tail_run(_ptr(xin), n, T, D, C.byref(r), _stream_ptr(self.device)))
+        return int(r.value)
+
+    def tied_violations(self) -> bool:
+        """True when a `tail_run` claim made to this tower since the last call was false (its outputs were NaN); clears it."""
+        v = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.tapclip_text_tied_violations(self.handle, C.byref(v), _stream_ptr(self.device)))
+        return bool(v.value)
+
     def forward(self, x: torch.Tensor, causal: bool = False, want_hidden: bool = True, want_heads: bool = False,
-                want_mean: bool = False, want_attn_out: bool = False):
+                want_mean: bool = False, want_attn_out: bool = False, tail_run: int = 1):
         """`clip.model.transformer(x)` (reference models/model_wrapper.py:58,72) on [n,T,D].
-        Returns dict with any of hidden [n,T,D], attn_heads [n,H,T,T], attn_mean [n,T,T], attn_out [n,T,D]."""
+        Returns dict with any of hidden [n,T,D], attn_heads [n,H,T,T], attn_mean [n,T,T], attn_out [n,T,D].
+        tail_run > 1: the caller knows the last `tail_run` rows of every sequence to be identical (zero-padded prompts
+        without positional embedding); the tower then runs on the distinct rows only (include/tapclip.h "tied padding")."""
         D = self.dims.width
         if x.dim() != 3 or x.shape[-1] != D:
             raise ValueError(f"expected x [n,T,{D}], got {tuple(x.shape)}")
@@ -170,10 +206,15 @@ class TextTower(_Tower):
         heads = mk(n, self.dims.heads, T, T) if want_heads else None
         mean = mk(n, T, T) if want_mean else None
         aout = mk(n, T, D) if want_attn_out else None
+        tail_run = self._check_tail_run(tail_run, T, causal)
         with torch.cuda.device(self.device):
-            ws, nbytes = self.workspace(n, T)
-            self._check(self.lib.tapclip_text_forward(self.handle, _ptr(xin), n, T, int(causal), _ptr(hidden), _ptr(heads),
-                                                     _ptr(mean), _ptr(aout), _ptr(ws), nbytes, _stream_ptr(self.device)))
+            ws, nbytes = self.workspace(n, T, tail_run)
+            if tail_run > 1:
+                self._check(self.lib.tapclip_text_forward_tied(self.handle, _ptr(xin), n, T, tail_run, _ptr(hidden), _ptr(heads),
+                                                              _ptr(mean), _ptr(aout), _ptr(ws), nbytes, _stream_ptr(self.device)))
+            else:
+                self._check(self.lib.tapclip_text_forward(self.handle, _ptr(xin), n, T, int(causal), _ptr(hidden), _ptr(heads),
+                                                         _ptr(mean), _ptr(aout), _ptr(ws), nbytes, _stream_ptr(self.device)))
         return {"hidden": hidden, "attn_heads": heads, "attn_mean": mean, "attn_out": aout}
 
     def pool_project(self, hidden: torch.Tensor, index: Optional[torch.Tensor] = None, ln_final: bool = False,
@@ -205,28 +246,40 @@ class TextTower(_Tower):
                                                       _ptr(self._ws), self._ws.numel(), _stream_ptr(self.device)))
         return out
 
-    def forward_saved(self, x: torch.Tensor, causal: bool = False):
+    def forward_saved(self, x: torch.Tensor, causal: bool = False, tail_run: int = 1):
         """Training forward: hidden [n,T,D] plus an opaque buffer of saved activations for `backward_saved`
-        (no attention write-back; `tapclip_text_forward_saved`)."""
+        (no attention write-back; `tapclip_text_forward_saved` / `_tied`: the same `tail_run` goes to `backward_saved`)."""
         xin = _dev_f32(x, self.device)
         n, T, D = xin.shape
+        tail_run = self._check_tail_run(tail_run, T, causal)
         hidden = torch.empty_like(xin)
         with torch.cuda.device(self.device):
-            saved = torch.empty(int(self.lib.tapclip_text_saved_bytes(self.handle, n, T)), dtype=torch.uint8, device=self.device)
-            ws, nbytes = self.workspace(n, T)
-            self._check(self.lib.tapclip_text_forward_saved(self.handle, _ptr(xin), n, T, int(causal), _ptr(hidden), _ptr(saved),
-                                                           saved.numel(), _ptr(ws), nbytes, _stream_ptr(self.device)))
+            saved = torch.empty(int(self.lib.tapclip_text_saved_bytes(self.handle, n, T - tail_run + 1)), dtype=torch.uint8,
+                                device=self.device)
+            ws, nbytes = self.workspace(n, T, tail_run)
+            if tail_run > 1:
+                self._check(self.lib.tapclip_text_forward_saved_tied(self.handle, _ptr(xin), n, T, tail_run, _ptr(hidden), _ptr(saved),
+                                                                    saved.numel(), _ptr(ws), nbytes, _stream_ptr(self.device)))
+            else:
+                self._check(self.lib.tapclip_text_forward_saved(self.handle, _ptr(xin), n, T, int(causal), _ptr(hidden), _ptr(saved),
+                                                               saved.numel(), _ptr(ws), nbytes, _stream_ptr(self.device)))
         return hidden, saved
 
-    def backward_saved(self, saved: torch.Tensor, grad_hidden: torch.Tensor, causal: bool = False) -> torch.Tensor:
-        """dL/dx from the activations kept by `forward_saved` (no recomputation; `tapclip_text_backward_saved`)."""
+    def backward_saved(self, saved: torch.Tensor, grad_hidden: torch.Tensor, causal: bool = False, tail_run: int = 1) -> torch.Tensor:
+        """dL/dx from the activations kept by `forward_saved` (no recomputation; `tapclip_text_backward_saved` / `_tied`).
+        tail_run > 1: the tied rows are one variable -- its gradient comes back in the run's first row, zeros behind it."""
         g = _dev_f32(grad_hidden, self.device)
         n, T, D = g.shape
+        tail_run = self._check_tail_run(tail_run, T, causal)
         out = torch.empty_like(g)
         with torch.cuda.device(self.device):
-            ws, nbytes = self.workspace(n, T)
-            self._check(self.lib.tapclip_text_backward_saved(self.handle, _ptr(saved), saved.numel(), _ptr(g), n, T, int(causal),
-                                                            _ptr(out), _ptr(ws), nbytes, _stream_ptr(self.device)))
+            ws, nbytes = self.workspace(n, T, tail_run)
+            if tail_run > 1:
+                self._check(self.lib.tapclip_text_backward_saved_tied(self.handle, _ptr(saved), saved.numel(), _ptr(g), n, T, tail_run,
+                                                                     _ptr(out), _ptr(ws), nbytes, _stream_ptr(self.device)))
+            else:
+                self._check(self.lib.tapclip_text_backward_saved(self.handle, _ptr(saved), saved.numel(), _ptr(g), n, T, int(causal),
+                                                                _ptr(out), _ptr(ws), nbytes, _stream_ptr(self.device)))
         return out
 
     def pool_project_backward(self, hidden: torch.Tensor, grad_out: torch.Tensor, normalize: bool = True) -> torch.Tensor:

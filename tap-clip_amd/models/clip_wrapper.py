@@ -80,14 +80,18 @@ class _TextTransformer(_Bag):
         super().__init__()
         object.__setattr__(self, "_owner", owner)
 
-    def capture(self, x: torch.Tensor) -> None:
+    def capture(self, x: torch.Tensor, _tail_run: int = 1) -> None:
         """The call of reference models/model_wrapper.py:58: the transformer is run for the hook's capture only and its
         output is discarded -- so the last block stops after its attention.  Routed through nn.Module.__call__ like
         the reference's `clip.model.transformer(prompts)`, so forward / pre-forward hooks a user registered on
         `clip.model.transformer` fire for this pass too (they see `None` as the output: there is no hidden state)."""
-        self(x, _need_hidden=False)
+        self(x, _need_hidden=False, _tail_run=_tail_run)
 
-    def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None, _need_hidden: bool = True) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None, _need_hidden: bool = True,
+                _tail_run: int = 1) -> torch.Tensor:
+        """_tail_run (keyword of this build, default 1 = off): the caller knows the last `_tail_run` rows of every sequence
+        to be identical -- zero-padded prompts carry one embedding row in every padding position and nothing here adds a
+        position -- and the tower then runs on the distinct rows only (engine.TextTower.forward; same outputs)."""
         own = self._owner
         causal = False
         if attn_mask is not None:
@@ -100,7 +104,7 @@ class _TextTransformer(_Bag):
         user_hooks = len(attn_mod._forward_hooks) > 0
         intended = own.attn_semantics == "intended"
         r = own._text.forward(x, causal=causal, want_hidden=_need_hidden, want_heads=user_hooks and intended,
-                              want_mean=intended, want_attn_out=not intended)
+                              want_mean=intended, want_attn_out=not intended, tail_run=1 if causal else _tail_run)
         if intended:
             own.attention_maps.append(r["attn_mean"])               # [n, T, T]
         else:

@@ -20,6 +20,7 @@ keys.  What changes is HOW the text side is evaluated:
   those of the global batch on every rank.
 """
 import math
+import os
 from typing import Optional
 
 import torch
@@ -37,13 +38,14 @@ class _TextTowerFn(torch.autograd.Function):
     backward: d(pool, projection, norm) and dX through the 12 frozen blocks (`tapclip_text_backward`)."""
 
     @staticmethod
-    def forward(ctx, prompts, clip):
+    def forward(ctx, prompts, clip, tail_run=1):
         tower = clip._text
         # the blocks keep their activations for the backward (no recomputation); like the reference's second
         # pass (model_wrapper.py:72) this call also leaves a capture in clip.attention_maps -- not needed here,
         # so the hook list is left as pass 1 filled it
-        hidden, saved = tower.forward_saved(prompts.detach())
+        hidden, saved = tower.forward_saved(prompts.detach(), tail_run=tail_run)
         ctx.tower = tower
+        ctx.tail_run = tail_run
         ctx.save_for_backward(hidden, saved)
         return tower.pool_project(hidden, index=None, ln_final=False, normalize=True)
 
@@ -51,7 +53,9 @@ class _TextTowerFn(torch.autograd.Function):
     def backward(ctx, grad_feat):
         hidden, saved = ctx.saved_tensors
         g_hidden = ctx.tower.pool_project_backward(hidden, grad_feat.contiguous(), normalize=True)
-        return ctx.tower.backward_saved(saved, g_hidden), None
+        # (tail_run > 1: the gradient of the tied padding rows comes back summed in the run's first row -- those rows
+        # are the frozen token bank's, nothing reads them; the context rows get the untied gradients)
+        return ctx.tower.backward_saved(saved, g_hidden, tail_run=ctx.tail_run), None, None
 
 
 class _LogitsFn(torch.autograd.Function):
@@ -75,7 +79,8 @@ class _LogitsFn(torch.autograd.Function):
 class FullModel(nn.Module):
     def __init__(self, class_names, clip_wrapper, prompt_len=5, attr_lambda=1.0, stab_lambda=0.1,
                  adjustor_method='scale', class_specific=False, *, collapse_text: bool = True,
-                 gather_images: bool = False, overlap_towers: bool = True, cache_text_features: bool = False):
+                 gather_images: bool = False, overlap_towers: bool = True, cache_text_features: bool = False,
+                 tie_padding: bool = True):
         super().__init__()
         self.clip = clip_wrapper
         self.class_names = class_names
@@ -105,6 +110,12 @@ class FullModel(nn.Module):
         # The reference recomputes them for every batch (model_wrapper.py:47-75).
         self.cache_text_features = cache_text_features
         self._text_cache = None
+        # The padding positions of every class prompt carry ONE embedding row (zero-padded token ids, reference
+        # prompt_learner.py:31-33) and the transformer is fed without position or mask (model_wrapper.py:58,72): those rows
+        # stay identical through every block, so the collapsed text path merges them -- 26 instead of 93 rows per sequence
+        # at BASELINE configs[2], same logits, maps and gradients (include/tapclip.h "tied padding rows").  False runs
+        # every row, as the literal replay always does.
+        self.tie_padding = tie_padding and os.environ.get("TAPCLIP_TIE_PADDING", "1") != "0"  # (the variable: A/B runs of tools/)
         # a checkpoint that carries other `clip.model.*` weights re-packs the towers (clip_wrapper.py here);
         # the frozen class-token embeddings derived from them are then re-computed as well
         self._clip_version = getattr(clip_wrapper, "weights_version", 0)
@@ -130,17 +141,33 @@ class FullModel(nn.Module):
             self.clip = clip
 
         def __enter__(self):
-            depth = getattr(self.clip, "_forward_gemms_depth", 0)
-            self.clip._forward_gemms_depth = depth + 1
-            if depth == 0:
-                for t in (self.clip._vision, self.clip._text):
-                    t.set_ksplit(False)
+            clip = self.clip
+            if getattr(clip, "_forward_gemms_depth", 0) == 0:
+                # what each tower was set to BEFORE this forward (a caller may have chosen 0 for a tower that shares the
+                # GPU): that, not the library default, is what __exit__ puts back.  The depth is only bumped once both
+                # flags are set, so a failing call leaves nothing half-entered.
+                towers = (clip._vision, clip._text)
+                before = [t.get_ksplit() for t in towers]
+                done = []
+                try:
+                    for t in towers:
+                        t.set_ksplit(False)
+                        done.append(t)
+                except Exception:
+                    for t, v in zip(done, before):
+                        t.set_ksplit(v)
+                    raise
+                clip._forward_gemms_saved = list(zip(towers, before))
+            clip._forward_gemms_depth = getattr(clip, "_forward_gemms_depth", 0) + 1
 
         def __exit__(self, *exc):
-            self.clip._forward_gemms_depth -= 1
-            if self.clip._forward_gemms_depth == 0:  # (the towers may have been re-packed meanwhile: address them anew)
-                for t in (self.clip._vision, self.clip._text):
-                    t.set_ksplit(True)
+            clip = self.clip
+            clip._forward_gemms_depth -= 1
+            if clip._forward_gemms_depth == 0:
+                live = (clip._vision, clip._text)  # (the towers may have been re-packed meanwhile: address them anew)
+                for (old, v), t in zip(clip._forward_gemms_saved, live):
+                    t.set_ksplit(v)
+                clip._forward_gemms_saved = []
             return False
 
     # ---- image side ----------------------------------------------------------------------------
@@ -193,9 +220,10 @@ class FullModel(nn.Module):
         ctx, tok = pl.stacked_context().detach(), pl.stacked_tokens()
         fused = self.prompt_adjustor.method == "scale"
 
+        run = self._tail_run()
         # pass 1: only for the attention capture (model_wrapper.py:57-62)
         clip.reset()
-        clip.model.transformer.capture(engine.build_prompts(ctx, tok))
+        clip.model.transformer.capture(engine.build_prompts(ctx, tok), _tail_run=run)
         attn_map = clip.get_attention_map()
         if attn_map.dim() == 2:
             attn_map = attn_map.unsqueeze(1)  # per sample [1,D] -> [1,1,D] in the reference (:60-61)
@@ -206,9 +234,12 @@ class FullModel(nn.Module):
             adjusted = engine.build_prompts(ctx, tok, attribution)
         else:
             adjusted = torch.cat([self.prompt_adjustor(ctx, attribution), tok], dim=1)
-        hidden = clip.model.transformer(adjusted)
+        hidden = clip.model.transformer(adjusted, _tail_run=run)
         self.last_attribution = attribution
         return clip._text.pool_project(hidden, index=None, ln_final=False, normalize=True)
+
+    def _tail_run(self) -> int:
+        return self.prompt_learner.tail_run() if self.tie_padding else 1
 
     def _forward_literal(self, images: torch.Tensor) -> torch.Tensor:
         """The reference loop nest as written (model_wrapper.py:47-83), on the HIP towers."""
@@ -246,15 +277,16 @@ class FullModel(nn.Module):
             with torch.no_grad():
                 image_feat, side = self._image_features_begin(images)
                 ctx_c, tok = pl.stacked_context().detach(), pl.stacked_tokens()
+                run = self._tail_run()
                 clip.reset()
-                clip.model.transformer.capture(engine.build_prompts(ctx_c, tok))
+                clip.model.transformer.capture(engine.build_prompts(ctx_c, tok), _tail_run=run)
                 attn_map = clip.get_attention_map()
                 if attn_map.dim() == 2:
                     attn_map = attn_map.unsqueeze(1)
                 attribution = self.attribution_monitor(attn_map)
             ctx = pl.stacked_context()                                   # differentiable w.r.t. every context_bank entry
             adjusted = torch.cat([self.prompt_adjustor(ctx, attribution), tok], dim=1)
-            text_feat = _TextTowerFn.apply(adjusted, clip)
+            text_feat = _TextTowerFn.apply(adjusted, clip, run)
         with torch.no_grad():
             image_feat = self._image_features_end(image_feat, side)
             image_feat, labels = self._gather(image_feat, labels)
@@ -293,7 +325,8 @@ class FullModel(nn.Module):
             if not self.collapse_text:
                 if self.gather_images:
                     raise RuntimeError("FullModel(collapse_text=False) is single-process (parity replay of the reference loop)")
-                logits = self._forward_literal(images)
+                with FullModel._ForwardGemms(self.clip):  # (same summation order as the collapsed forward)
+                    logits = self._forward_literal(images)
                 labels = None if labels is None else labels.to(logits.device)
             else:
                 with FullModel._ForwardGemms(self.clip):

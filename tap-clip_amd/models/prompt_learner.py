@@ -14,6 +14,12 @@ import torch
 import torch.nn as nn
 
 
+def host_tail_run(tok: torch.Tensor) -> int:
+    """Largest r such that the last r rows of every sequence of tok [n, L, D] are identical (>= 1), counted on the host."""
+    same = (tok == tok[:, -1:, :]).all(dim=-1).flip(1).long().cumprod(dim=1).sum(dim=1)
+    return int(same.min())
+
+
 class PromptLearner(nn.Module):
     def __init__(self, class_names, clip_model, prompt_len=5, class_specific=True, use_init_prompt=True, device=None):
         super().__init__()
@@ -28,6 +34,7 @@ class PromptLearner(nn.Module):
         self.context_bank = nn.ParameterDict()          # class name -> [P, D], trainable
         self.token_bank: Dict[str, torch.Tensor] = {}   # class name -> [1, 77, D], frozen
         self._tok_cache: Optional[torch.Tensor] = None
+        self._tail_run: Optional[int] = None
 
         print(f"cls_specific: {class_specific}, use_init_prompt: {use_init_prompt}")
         for name in class_names:
@@ -51,6 +58,7 @@ class PromptLearner(nn.Module):
             init = torch.randn(self.prompt_len, self.ctx_dim).to(self.device)
         self.context_bank[class_name] = nn.Parameter(init)
         self._tok_cache = None
+        self._tail_run = None
 
     @torch.no_grad()
     def refresh_token_bank(self) -> None:
@@ -59,6 +67,7 @@ class PromptLearner(nn.Module):
             ids = self.tokenizer(f"a photo of a {class_name}").to(self.device)
             self.token_bank[class_name] = self.token_embedding(ids.unsqueeze(0)).squeeze(0)
         self._tok_cache = None
+        self._tail_run = None
 
     # ---- stacked views for the fused path ----------------------------------------------------
     def stacked_context(self) -> torch.Tensor:
@@ -80,6 +89,21 @@ class PromptLearner(nn.Module):
                 rows.append(t)
             self._tok_cache = torch.cat(rows, dim=0)
         return self._tok_cache
+
+    def tail_run(self) -> int:
+        """How many trailing rows of EVERY class prompt are one and the same row: the tokenizer pads each prompt with zeros
+        to 77 ids (reference prompt_learner.py:31-33) and `token_embedding` maps them all to one row.  FullModel feeds these
+        sequences to a transformer that adds neither position nor mask (reference model_wrapper.py:58,72), so the run is
+        merged there (`_TextTransformer.forward(_tail_run=)`).  Measured on the device once per token bank; at most
+        76, so that the run never reaches into the context rows."""
+        if self._tail_run is None:
+            tok = self.stacked_tokens()
+            if tok.is_cuda and hasattr(self.token_embedding, "_owner"):
+                r = self.token_embedding._owner._text.tail_run(tok)
+            else:  # (a token bank that does not live on the GPU: count on the host)
+                r = host_tail_run(tok)
+            self._tail_run = max(1, min(r, tok.shape[1] - 1))
+        return self._tail_run
 
     def forward(self) -> torch.Tensor:
         """[n_cls, P + 77, D]: context tokens first, then the class prompt's token embeddings."""

@@ -265,3 +265,64 @@ def test_fitted_gelu_is_within_its_stated_bound_of_the_exact_form():
     # saturated tails: the clamp inside the polynomial freezes the sigmoid at 2^-28.4, so the fit returns x * 2.9e-9 where
     # the exact form returns 0 -- below 3e-7 for |x| <= 100 (no MLP pre-activation of CLIP comes near), 2.9e-5 at -1e4
     assert float(err[(x.abs() > 9) & (x.abs() <= 100)].max()) < 3e-7
+
+
+def test_tied_padding_rows_collapse_reproduces_the_reference_fullmodel():
+    """The identity behind the tied-padding path of the HIP text tower (tap-clip_amd/csrc/tied.hip), checked against the
+    REFERENCE's own FullModel at BASELINE configs[2]: its prompts are [16 context rows | token_embedding(zero-padded ids)]
+    (reference models/prompt_learner.py:31-34,62-65) and its transformer calls add neither position nor mask (reference
+    models/model_wrapper.py:58,72), so the 68-70 padding rows of every sequence are one row repeated.  Running the oracle
+    towers on the 26 distinct rows, with ln(run) added to the last key's score, must give the reference's logits, map
+    columns and attribution (goldens written by the reference's classes on all 93 rows)."""
+    from tap_clip_amd.models.prompt_learner import host_tail_run
+
+    g = golden("fullmodel_intended_vitb16_c65")
+    cfg = clip_ref.CONFIGS["ViT-B-16"]
+    sd = synth.make_state_dict(cfg, seed=int(g["seed_weights"]))
+    P, n = int(g["prompt_len"]), len(g["class_names"])
+    tok = sd["token_embedding.weight"][torch.from_numpy(g["token_ids"])]
+    ctx = synth.make_prompts(n, P, cfg, seed=int(g["seed_context"]))[0]
+    prompts = torch.cat([ctx, tok], dim=1)
+    T = prompts.shape[1]
+    run = host_tail_run(tok)
+    Tc = T - run + 1
+    assert (run, Tc) == (68, 26)
+    key_bias = torch.zeros(Tc, Tc)
+    key_bias[:, -1] = math.log(run)                     # the merged key counts `run` times: exp(s + ln m) = m exp(s)
+
+    def tower(x, want_probs=False):
+        return clip_ref.transformer_forward(x, sd, "transformer.", cfg.text.layers, cfg.text.heads, key_bias,
+                                            cfg.quick_gelu, None, want_last_probs=want_probs)
+
+    with torch.no_grad():
+        _, probs, _ = tower(prompts[:, :Tc], want_probs=True)
+        amc = probs.mean(dim=1)                          # [n, Tc, Tc]
+        amap = torch.empty(n, T, T)
+        amap[:, :Tc, :Tc - 1] = amc[:, :, :Tc - 1]
+        amap[:, :Tc, Tc - 1:] = (amc[:, :, Tc - 1:] / run).expand(-1, -1, run)
+        amap[:, Tc:, :] = amap[:, Tc - 1:Tc, :]
+        assert rel_max(amap[:8], torch.from_numpy(g["attn_map_head"])) < 2e-5
+        assert rel_max(amap[:, :, -1], torch.from_numpy(g["attn_map_last_col"])) < 2e-5
+        attr = full_model_ref.attribution_from_map(amap, P)
+        assert rel_max(attr, torch.from_numpy(g["attribution"])) < 1e-5
+        adjusted = torch.cat([full_model_ref.adjust_scale(ctx, attr), tok], dim=1)[:, :Tc]
+        hidden, _, _ = tower(adjusted)
+        feat = hidden[:, -1, :] @ sd["text_projection"]
+        feat = feat / feat.norm(dim=-1, keepdim=True)
+        images = synth.make_images(int(g["batch"]), cfg, int(g["seed_images"]))
+        img = clip_ref.encode_image(images, sd, cfg, normalize=True)
+        logits = math.exp(math.log(1 / 0.07)) * img @ feat.t()
+    assert rel_max(logits, torch.from_numpy(g["logits"])) < 2e-5
+
+
+def test_host_tail_run():
+    from tap_clip_amd.models.prompt_learner import host_tail_run
+
+    tok = torch.randn(3, 10, 4)
+    assert host_tail_run(tok) == 1
+    tok[:, 6:] = tok[:, -1:]
+    tok[1, 4:] = tok[1, -1]
+    assert host_tail_run(tok) == 4
+    tok[2, 8] += 1.0
+    assert host_tail_run(tok) == 1
+    assert host_tail_run(torch.ones(2, 5, 3)) == 5

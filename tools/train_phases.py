@@ -7,7 +7,8 @@ from tap_clip_amd.models import CLIPWrapper, FullModel
 dev = "cuda:0"
 cfg = configs.get_config("ViT-B-16")
 sd = synth.make_state_dict(cfg, seed=2)
-clip = CLIPWrapper("ViT-B-16", None, dev, precision="bf16", state_dict=sd)
+prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+clip = CLIPWrapper("ViT-B-16", None, dev, precision=prec, state_dict=sd)
 names = [f"class{i}" for i in range(65)]
 model = FullModel(names, clip, prompt_len=16, class_specific=True).to(dev)
 images = synth.make_images(256, cfg, 0).to(dev)
@@ -39,6 +40,7 @@ def text_grad():
     f = model.text_features(); return f
 def text_grad_bwd():
     f = model.text_features(); f.sum().backward()
+print(f"precision {prec}, tied padding run {model._tail_run()}")
 print(f"image tower alone                      {timeit(img_only):7.3f} ms")
 print(f"text features, no grad                 {timeit(text_only):7.3f} ms")
 print(f"forward, no grad (towers overlapped)   {timeit(fwd_only):7.3f} ms")
