@@ -8,7 +8,9 @@ One step = `encode_image` of the rank's 256 images (L2-normalised, reference
 models/model_wrapper.py:40-41) -> all-gather of the embeddings over RCCL (identity at N = 1) ->
 65-class cosine logits (model_wrapper.py:79,83) against text features computed ONCE before the timed
 region by the HIP text tower (they do not depend on the images).  value = images embedded per
-second by the whole job (weak scaling: 256 images per GPU).
+second by the whole job (weak scaling: 256 images per GPU).  The SECOND metric of BASELINE.json, logits/s, is
+SURVEY.md section 8d's: B * n_cls / t(FullModel.forward), both text passes inside the timed region, every row of
+every image block computed (top-level `logits_per_sec`, details under `full_forward`).
 
 Extra objects on the same line:
   roofline      dominant kernel = the bf16 MFMA GEMM (QKV / out-proj / c_fc+GELU / c_proj launches):
@@ -23,7 +25,12 @@ Extra objects on the same line:
                 split-bf16 everywhere, fp8 = MXFP8 block GEMMs), each with its embedding error against bf16x3 and the
                 error of its FullModel LOGITS against the CPU oracle; `parity_mode` names the fastest one inside 1e-3.
   full_forward  FullModel.forward at configs[2] (image + text towers, 65 classes, 16 context tokens,
-                attention-map write-back on): logits/s, measured after the timed region.
+                attention-map write-back on), on every rank (embeddings gathered inside the forward at N > 1): the
+                full computation (-> top-level logits_per_sec) and the library's default path beside it.
+  ranks         (N > 1) what the first multi-GPU run needs to be read: ranks RCCL saw, each rank's device, per-rank
+                min / median / max step time, the all-gather's own duration from HIP events.
+  configs4      BASELINE configs[4] at its per-GPU shape (ViT-L/14@336, fp8 MFMA, batch 128): encode img/s, fraction of
+                the 5 PFLOP/s MXFP8 peak, GEMM family, prompt-tuning step -- a bounded leg (--no-configs4 skips it).
   input_side    CLIP's eval transform (bicubic resize, crop, normalise) of uint8 photos on the GPU
                 (tapclip_preprocess_u8), with the reference's Pillow CPU path on one core beside it.
 """
@@ -84,6 +91,30 @@ def source_sha16():
     return h.hexdigest()[:16]
 
 
+def pmc_traffic(args, suffix=""):
+    """L2-fabric-side bytes per launch of the GEMM family from the newest committed PMC passes (separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE runs of this script, tools/pmc_traffic.py; `suffix` "" = the bf16 headline, "_fp16" = the
+    IEEE-half build ...) -> (bytes or None, note).  The passes are of the kernels as they were when they were taken: the
+    file names the GEMM sources it measured, and a library built from other sources reports null, not a stale figure."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r??_pmc_traffic_bench{suffix}.json")), reverse=True)
+    if not files or (args.batch, args.model) != (256, "ViT-B-16"):
+        return None, "no committed PMC pass for this configuration"
+    tname = os.path.basename(files[0])
+    try:
+        tj = json.load(open(files[0]))
+        want, have = tj.get("gemm_source_sha16"), source_sha16()
+        if want != have:
+            return None, (f"profiles/{tname} was measured on GEMM sources {want}, this library is built from {have}: "
+                          "traffic withheld until the PMC passes are re-run (tools/collect_profiles.sh)")
+        return tj.get("gemm_family_hbm_bytes_per_launch"), (
+            f"bytes/launch at the L2 fabric side (FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits included) from profiles/{tname}, "
+            "a separate rocprofv3 --pmc run; algorithmic operand+output bytes per launch average 313 MB")
+    except Exception as e:  # noqa: BLE001
+        return None, f"profiles/{tname} unreadable: {e}"
+
+
 def cgroup_cpu_quota():
     """CPUs the container may use per its cgroup quota (v2 cpu.max, v1 cpu.cfs_quota_us), or None without a quota."""
     try:
@@ -120,6 +151,95 @@ def spawn_ranks(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def configs4_leg(dev, events):
+    """BASELINE.json configs[4] at its per-GPU shape, inside the driver's own run: ViT-L/14@336, fp8 (MXFP8) MFMA image
+    tower, batch 128, and the prompt-tuning step of the reference's training loop (reference train.py:95-105; image encoder
+    frozen, prompt gradients only: 3 classes x 16 context tokens here, the text tower in bf16 beside the fp8 image tower).
+    A bounded leg: weights drawn on the device (synth.make_state_dict_device: nothing here is compared with a golden --
+    the fp8 parity tests are tests/test_gpu_mx8.py), few iterations.  Every row of every block is computed for `img_per_s`;
+    the train step runs the library defaults."""
+    import contextlib
+
+    import tap_clip_amd  # noqa: F401
+    from tap_clip_amd import configs, engine, synth
+    from tap_clip_amd.models import CLIPWrapper, FullModel
+
+    t_leg = time.perf_counter()
+    name, batch, n_cls, P = "ViT-L-14-336", 128, 65, 16
+    cfg = configs.get_config(name)
+    sd = synth.make_state_dict_device(cfg, seed=2, device=dev)
+    cw = CLIPWrapper(name, None, str(dev), precision="fp8", attn_semantics="intended", state_dict=sd)
+    del sd
+    tw = cw._vision
+    images = torch.randn(batch, 3, cfg.image_size, cfg.image_size, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+    flops = encoder_flops_per_image(cfg)
+
+    def timed(fn, its):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize(dev)
+        t_ = time.perf_counter()
+        for _ in range(its):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t_) / its
+
+    out = {"workload": f"BASELINE configs[4] per GPU: {name}, fp8 (MXFP8 e4m3 + e8m0/32) MFMA image tower, batch {batch}, synthetic "
+                       f"{cfg.image_size}x{cfg.image_size}x3; weights seeded on the device", "dtype": "fp8 (MXFP8) image tower, bf16 text tower"}
+    with torch.no_grad():
+        tw.set_prune_last_block(False)
+        dt = timed(lambda: tw.encode_image(images, normalize=True), 8)
+        out.update({"img_per_s": round(batch / dt, 1), "ms_per_step": round(1e3 * dt, 3),
+                    "encoder_gflop_per_image": round(flops / 1e9, 2),
+                    "encoder_mfma_frac": round(flops * batch / dt / (PEAK_FP8_TFLOPS * 1e12), 4), "peak_TFLOPs": PEAK_FP8_TFLOPS})
+        if events:
+            tw.profile(True)
+            tw.profile_read()
+            torch.cuda.synchronize(dev)
+            for _ in range(4):
+                tw.encode_image(images, normalize=True)
+            torch.cuda.synchronize(dev)
+            prof = tw.profile_read()
+            tw.profile(False)
+            gf = gemm_flops_per_image(cfg)
+            g_ms = sum(prof[k][0] for k in gf)
+            g_n = sum(prof[k][1] for k in gf)
+            g_fl = sum(gf[k] * batch * 4 for k in gf)
+            if g_ms > 0:
+                out["gemm_family"] = {"achieved": round(g_fl / (g_ms * 1e-3) / 1e12, 1), "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": round(g_fl / (g_ms * 1e-3) / 1e12 / PEAK_FP8_TFLOPS, 4), "avg_launch_us": round(1e3 * g_ms / g_n, 2),
+                                      "per_family": {k: {"avg_us": round(1e3 * prof[k][0] / max(prof[k][1], 1), 1),
+                                                         "tflops": round(gf[k] * batch * 4 / (prof[k][0] * 1e-3) / 1e12, 1)} for k in gf if prof[k][1]}}
+            out["kernels_ms_per_step"] = {k: round(v[0] / 4, 3) for k, v in prof.items() if v[1]}
+        tw.set_prune_last_block(True)
+        dt_d = timed(lambda: tw.encode_image(images, normalize=True), 8)
+        out["img_per_s_default_path"] = round(batch / dt_d, 1)
+    names = [f"class_{i}" for i in range(n_cls)]
+    with contextlib.redirect_stdout(sys.stderr):
+        fm = FullModel(names, cw, prompt_len=P, class_specific=True)
+    labels = torch.arange(batch, device=dev) % n_cls
+    opt = torch.optim.AdamW(fm.prompt_learner.parameters(), lr=2e-3, weight_decay=0.01)
+    fm.train()
+
+    def train_step():
+        o = fm(images, labels)
+        opt.zero_grad(set_to_none=True)
+        o["loss"].backward()
+        opt.step()
+
+    dt_t = timed(train_step, 5)
+    fm.eval()
+    with torch.no_grad():
+        dt_f = timed(lambda: fm(images), 5)
+    out["full_forward_ms"] = round(1e3 * dt_f, 3)
+    out["train_step_ms"] = round(1e3 * dt_t, 3)
+    out["train_step"] = f"reference train.py:95-105 loop body at {n_cls} classes x {P} context tokens: forward, CE, backward to the prompts, AdamW"
+    out["leg_seconds"] = round(time.perf_counter() - t_leg, 1)
+    del fm, opt, cw, tw, images
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,6 +256,7 @@ def main():
     ap.add_argument("--no-input-side", action="store_true", help="skip the GPU preprocess measurement")
     ap.add_argument("--no-precisions", action="store_true", help="skip the bf16 / fp16 / fp8 comparison table")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--no-configs4", action="store_true", help="skip the ViT-L/14@336 fp8 batch-128 leg (BASELINE configs[4])")
     ap.add_argument("--dump-logits", default=None, help="rank 0 saves the last step's [global_batch, classes] logits here (.npy): tests")
     args = ap.parse_args()
 
@@ -211,28 +332,46 @@ def main():
     for _ in range(args.warmup):
         step()
     events = not args.no_kernel_events
+    # one HIP event per step boundary on the launch stream (a ~1 us host call every ~11 ms): per-step durations of THIS
+    # rank for the `ranks` table -- the first multi-GPU run must show which rank, if any, is the slow one
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    step_ev[0].record()
+    for i in range(args.steps):
         out = step()
+        step_ev[i + 1].record()
     sync_all()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps))
     # Second pass of the same K steps with a HIP event pair around every kernel family (recorded on the launch
     # stream by the library, tapclip_profile_*): the per-kernel durations of the roofline object.  It is a pass
     # of its own because ~100 event records per step cost ~5 % of the step; `value` is the clean pass above.
     prof = None
     elapsed_events = None
+    gather_us = None
     if events:
         vision.profile(True)
         vision.profile_read()
+        ag = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if world > 1 else []
         sync_all()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        for i in range(args.steps):
+            if world > 1:  # the exchange step's own duration on this rank's stream (the wait for the slowest rank included)
+                emb = vision.encode_image(images, normalize=True)
+                ag[i][0].record()
+                emb = all_gather_rows(emb)
+                ag[i][1].record()
+                engine.logits(emb, text_feat, scale)
+            else:
+                step()
         sync_all()
         elapsed_events = time.perf_counter() - t1
         prof = vision.profile_read()
         vision.profile(False)
+        if ag:
+            g_us = sorted(1e3 * a.elapsed_time(b) for a, b in ag)
+            gather_us = {"min": round(g_us[0], 1), "median": round(g_us[len(g_us) // 2], 1), "max": round(g_us[-1], 1)}
     # the library's default path (CLS-only last block) on the same step, same number of steps
     elapsed_default = None
     if pruning:
@@ -250,6 +389,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0].item())
         elapsed_default = float(t[1].item()) if pruning else None
+    ranks_info = None
+    if world > 1:
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "device": str(dev), "name": props.name, "uuid": str(getattr(props, "uuid", "")),
+                "pci": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0)),
+                "step_ms": {"min": round(step_ms[0], 3), "median": round(step_ms[len(step_ms) // 2], 3), "max": round(step_ms[-1], 3)},
+                "allgather_us": gather_us}
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, mine)
     assert out.shape == (args.batch * world, args.classes) and bool(torch.isfinite(out).all())
     if args.dump_logits and rank == 0:
         import numpy as np
@@ -273,12 +421,18 @@ def main():
                                   f"RCCL all_gather_into_tensor of the [{args.batch}, {cfg.embed_dim}] fp32 embeddings over xGMI" if backend == "nccl" else
                                   f"{backend} all_gather through host memory -- REHEARSAL, {world} ranks on "
                                   f"{torch.cuda.device_count()} GPU(s): not a scaling measurement")},
-        "logits_per_sec": round(value * args.classes, 1),
+        # B * n_cls / t(FullModel.forward) -- set by the full-forward leg below (null when it is skipped)
+        "logits_per_sec": None,
+        "step_ms": {"min": round(step_ms[0], 3), "median": round(step_ms[len(step_ms) // 2], 3), "max": round(step_ms[-1], 3),
+                    "what": "this rank's per-step durations from one HIP event per step boundary (rank 0 here; every rank under `ranks`)"},
         # against the dense peak of the headline precision's MFMA (bf16 / IEEE half: 2.5 PFLOP/s; fp8: the block-scaled 5 PFLOP/s)
         "encoder_mfma_frac": round(enc_flops * args.batch * world * args.steps / elapsed /
                                    ((PEAK_FP8_TFLOPS if args.precision == "fp8" else PEAK_BF16_TFLOPS) * 1e12 * world), 4),
         "encoder_gflop_per_image": round(enc_flops / 1e9, 3),
     }
+    if world > 1:
+        result["ranks"] = {"rccl_ranks_seen": dist.get_world_size(), "backend": dist.get_backend(), "visible_devices": torch.cuda.device_count(),
+                           "distinct_devices": len({(r["uuid"], r["pci"], r["device"]) for r in ranks_info}), "per_rank": ranks_info}
     if elapsed_default is not None:
         ex = encoder_flops_per_image(cfg, pruned_last_block=True)
         result["default_path"] = {
@@ -314,32 +468,9 @@ def main():
     if prof is not None:
         kern, g_ms, g_fl, g_n = kernel_table(prof, args.steps)
         achieved = g_fl / (g_ms * 1e-3) / 1e12
-        # L2-fabric-side bytes per launch of the same kernel family from the committed PMC passes (separate
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this script, tools/pmc_traffic.py); None if absent
-        traffic = None
-        tname = next((n for n in ("r03_pmc_traffic_bench.json", "r02_pmc_traffic_bench.json", "r01_pmc_traffic_bench.json")
-                      if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
-        traffic_note = "no committed PMC pass for this configuration"
-        if tname and args.batch == 256 and args.model == "ViT-B-16":
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", tname)))
-                traffic = tj.get("gemm_family_hbm_bytes_per_launch")
-                traffic_note = (f"bytes/launch at the L2 fabric side (FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits included) from profiles/{tname}, "
-                                "a separate rocprofv3 --pmc run; algorithmic operand+output bytes per launch average 313 MB")
-                # the PMC pass is of the kernels as they were when it was taken: it names the source it measured, and a
-                # library built from other GEMM sources reports null rather than a stale figure
-                want = tj.get("gemm_source_sha16")
-                have = source_sha16()
-                if want != have:
-                    traffic = None
-                    traffic_note = (f"profiles/{tname} was measured on GEMM sources {want}, this library is built from {have}: "
-                                    "traffic withheld until the PMC passes are re-run (tools/collect_profiles.sh)")
-            except Exception:
-                traffic = None
+        traffic, traffic_note = pmc_traffic(args, "" if args.precision == "bf16" else "_" + args.precision)
         fp8 = args.precision == "fp8"
         peak = PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS
-        if fp8:
-            traffic = None  # the committed PMC passes are of the bf16 kernels
         result["roofline"] = {
             "kernel": ("gemm_mx8_kernel<EPI> (persistent MXFP8 MFMA 32x32x64 GEMM, 256x256 tiles, 4-stage LDS-DMA ring with e8m0 scales): the QKV + out_proj + c_fc/GELU + c_proj launches"
                        if fp8 else
@@ -366,26 +497,52 @@ def main():
                                        "bytes_per_step": ln_bytes, "residual_stream": "24-bit planes" if x24 else "fp32"}
         result["kernels"] = kern
 
-    if rank == 0 and world == 1 and not args.no_full_forward:
-        with torch.no_grad():
-            for _ in range(2):
-                model(images)
-            torch.cuda.synchronize(dev)
-            n_it = max(10, args.steps // 4)  # (at the driver's --steps 20 five forwards were a noisy sample: 12.3 .. 12.7 ms)
-            t1 = time.perf_counter()
-            for _ in range(n_it):
-                lg = model(images)["logits"]
-            torch.cuda.synchronize(dev)
-            dt = (time.perf_counter() - t1) / n_it
+    def timed_all_ranks(fn, n_it):
+        """n_it calls of fn bracketed like the headline (barrier + synchronize on both sides), MAX over ranks, seconds per call"""
+        for _ in range(2):
+            fn()
+        sync_all()
+        t_ = time.perf_counter()
+        for _ in range(n_it):
+            fn()
+        sync_all()
+        d_ = (time.perf_counter() - t_) / n_it
+        if world > 1:
+            tt = torch.tensor([d_], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            d_ = float(tt.item())
+        return d_
+
+    if not args.no_full_forward:
+        # FullModel.forward on EVERY rank (at N > 1 the embeddings are gathered inside it, on the image tower's stream, beside
+        # the replicated text tower).  First with every row of every image block computed -- the figure the top-level
+        # logits_per_sec is made of -- then the library's default path (CLS-only last image block, same logits).
+        n_it = max(10, args.steps // 4)  # (at the driver's --steps 20 five forwards were a noisy sample: 12.3 .. 12.7 ms)
+        gb = args.batch * world
+
+        def fwd():
+            with torch.no_grad():
+                return model(images)["logits"]
+
+        vision.set_prune_last_block(False)
+        dt_full = timed_all_ranks(fwd, n_it)
+        vision.set_prune_last_block(True)
+        dt = timed_all_ranks(fwd, n_it)
         is_cfg2 = (args.model, args.batch, args.classes, args.prompt_len) == ("ViT-B-16", 256, 65, 16)
-        if True:
-            result["full_forward"] = {"workload": ("BASELINE configs[2]: " if is_cfg2 else "") +
-                                                  f"{args.model} image+text towers, {args.classes} classes, P={args.prompt_len}, "
-                                                  "attention-map write-back on, batch %d (library defaults: CLS-only last image block)" % args.batch,
-                                      "ms_per_forward": round(1e3 * dt, 3), "logits_per_sec": round(args.batch * args.classes / dt, 1),
-                                      "images_per_sec": round(args.batch / dt, 1)}
-        # prompt-tuning step (reference train.py:99-105): forward + loss + backward to context_bank + AdamW
-        labels = synth.make_labels(args.batch, args.classes).to(dev)
+        result["logits_per_sec"] = round(gb * args.classes / dt_full, 1)
+        result["full_forward"] = {
+            "workload": ("BASELINE configs[2]: " if is_cfg2 else "") + f"{args.model} image+text towers, {args.classes} classes, P={args.prompt_len}, "
+                        f"attention-map write-back on, batch {args.batch}/GPU; FullModel.forward with BOTH text passes inside the timed region"
+                        + (f", embeddings all-gathered inside the forward over {world} ranks (max over ranks)" if world > 1 else ""),
+            "ms_per_forward": round(1e3 * dt_full, 3), "logits_per_sec": round(gb * args.classes / dt_full, 1),
+            "images_per_sec": round(gb / dt_full, 1), "cls_only_last_block": False,
+            "text_rows_per_sequence": {"input": args.prompt_len + cfg.ctx, "computed": args.prompt_len + cfg.ctx - model._tail_run() + 1,
+                                       "why": "the padding rows of a prompt are one embedding row repeated and the reference adds no position / mask "
+                                              "(models/model_wrapper.py:58,72): the text tower runs on the distinct rows (include/tapclip.h, tied padding rows)"},
+            "default_path": {"ms_per_forward": round(1e3 * dt, 3), "logits_per_sec": round(gb * args.classes / dt, 1),
+                             "images_per_sec": round(gb / dt, 1), "cls_only_last_block": True}}
+        # prompt-tuning step (reference train.py:99-105): forward + loss + backward to context_bank + AdamW, library defaults
+        labels = synth.make_labels(args.batch, args.classes, seed=3 + rank).to(dev)
         opt = torch.optim.AdamW(model.prompt_learner.parameters(), lr=2e-3, weight_decay=0.01)
         model.train()
 
@@ -395,19 +552,16 @@ def main():
             out_t["loss"].backward()
             opt.step()
 
-        for _ in range(2):
-            train_step()
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        for _ in range(n_it):
-            train_step()
-        torch.cuda.synchronize(dev)
-        dt_t = (time.perf_counter() - t1) / n_it
+        dt_t = timed_all_ranks(train_step, n_it)
         model.eval()
+        del opt
+        with torch.no_grad():  # back to the SEEDED prompts: every check below is made at that point, whatever --steps was
+            for i, c in enumerate(names):
+                model.prompt_learner.context_bank[c].copy_(ctx[i])
         result["train_step"] = {"workload": f"prompt-tuning step ({args.model}): FullModel forward + CE + backward to {args.classes} x "
                                             f"[{args.prompt_len},{cfg.text.width}] context tokens + AdamW, "
-                                            "batch %d (image tower forward only: frozen; library defaults: CLS-only last image block)" % args.batch,
-                                "ms_per_step": round(1e3 * dt_t, 3), "images_per_sec": round(args.batch / dt_t, 1)}
+                                            "batch %d/GPU (image tower forward only: frozen; library defaults: CLS-only last image block)" % args.batch,
+                                "ms_per_step": round(1e3 * dt_t, 3), "images_per_sec": round(gb / dt_t, 1)}
     if rank == 0 and world == 1 and not args.no_input_side:
         # Input side: CLIP's eval transform of decoded uint8 photos on the GPU, bit-identical to the
         # Pillow + torchvision transform the reference runs per sample in its loader workers (dataset.py:29-35).
@@ -508,9 +662,12 @@ def main():
             med = sorted(times)[1]
             # row 3 of BASELINE.md section 3: the full forward (collapsed text side), batch 32
             prompts = model.prompt_learner().detach().cpu() if model is not None else None
-            t1 = time.perf_counter()
-            o_full = full_model_ref.forward_collapsed(sample, prompts, args.prompt_len, sd, ocfg, attn_semantics="intended")
-            t_full = time.perf_counter() - t1
+            t_fulls = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                o_full = full_model_ref.forward_collapsed(sample, prompts, args.prompt_len, sd, ocfg, attn_semantics="intended")
+                t_fulls.append(time.perf_counter() - t1)
+            t_full = sorted(t_fulls)[1]
             oracle_logits = o_full["logits"]
             # row 1: BASELINE configs[0] as the reference runs it -- ViT-B/32, batch 8, 10 classes, P = 5, the literal
             # per-sample attribution loop (reference models/model_wrapper.py:47-83): 10 x (8 + 1) text passes
@@ -534,7 +691,7 @@ def main():
                                       "cfg1_literal_loop": {"workload": "BASELINE configs[0]: ViT-B-32, batch 8, 10 classes, P=5 (T=82), literal per-sample attribution loop (oracle/full_model_ref.forward_literal), 1 run",
                                                             "seconds": round(t_lit, 3), "logits_per_sec": round(80 / t_lit, 2), "images_per_sec": round(8 / t_lit, 3)},
                                       "image_tower": {"workload": f"{args.model} image tower fp32, batch {n_ref}", "images_per_sec": round(n_ref / med, 2)},
-                                      "full_forward_collapsed": {"workload": f"{args.model} full forward, {args.classes} classes, P={args.prompt_len}, collapsed text path (oracle/full_model_ref.forward_collapsed), batch {n_ref}, 1 run",
+                                      "full_forward_collapsed": {"workload": f"{args.model} full forward, {args.classes} classes, P={args.prompt_len}, collapsed text path (oracle/full_model_ref.forward_collapsed), batch {n_ref}, median of 3",
                                                                  "seconds": round(t_full, 3), "logits_per_sec": round(n_ref * args.classes / t_full, 1),
                                                                  "images_per_sec": round(n_ref / t_full, 2)}}}
 
@@ -586,7 +743,7 @@ def main():
                     if g_ms_p > 0:
                         row["gemm_family"] = {"achieved": round(g_fl_p / (g_ms_p * 1e-3) / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                               "frac": round(g_fl_p / (g_ms_p * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-                                              "avg_launch_us": round(1e3 * g_ms_p / g_n_p, 2)}
+                                              "avg_launch_us": round(1e3 * g_ms_p / g_n_p, 2), "flops_per_launch": round(g_fl_p / g_n_p)}
                 tw.set_prune_last_block(True)  # the shipped default: its speed, and the errors below are ITS errors
                 for _ in range(2):
                     tw.encode_image(images, normalize=True)
@@ -640,7 +797,12 @@ def main():
                     row["logits_rel_max_vs_cpu_oracle"] = float("%.3e" % float(err.max() / oracle_logits.abs().max()))
                     row["logits_rel_l2_vs_cpu_oracle"] = float("%.3e" % float(err.norm() / oracle_logits.norm()))
                     row["meets_1e-3"] = bool(err.max() / oracle_logits.abs().max() < 1e-3)
-                    row["top1_agreement_vs_cpu_oracle"] = round(float((lg.argmax(1) == oracle_logits.argmax(1)).float().mean()), 4)
+                    # how the error compares with what decides a prediction: per image, its largest logit error over the
+                    # oracle's top-1 / top-2 margin (>= 0.5 can flip the arg-max; on this random-weight model the margins
+                    # themselves are small, which is why arg-max agreement says little here)
+                    top2 = oracle_logits.topk(2, dim=1).values
+                    ratio = err.max(dim=1).values / (top2[:, 0] - top2[:, 1]).clamp_min(1e-12)
+                    row["logits_err_over_top2_margin"] = {"median": float("%.3e" % float(ratio.median())), "max": float("%.3e" % float(ratio.max()))}
                 del fm
                 table[prec] = row
                 print(f"[bench] precision {prec} done at {time.perf_counter() - t_start:.1f}s", file=sys.stderr, flush=True)
@@ -648,18 +810,39 @@ def main():
                     del cw, tw
                     torch.cuda.empty_cache()
         result["precisions"] = table
+        if args.precision in table and "meets_1e-3" in table[args.precision]:
+            # does the HEADLINE number's own mode hold BASELINE.json's 1e-3 on the FullModel logits?  (bf16 does not: it is the
+            # precision configs[1] names and a throughput figure; `parity_mode` below is the line that holds both.)
+            result["headline_meets_tolerance"] = table[args.precision]["meets_1e-3"]
+            result["headline_logits_rel_max_vs_cpu_oracle"] = table[args.precision]["logits_rel_max_vs_cpu_oracle"]
         ok = [k for k, v in table.items() if v.get("meets_1e-3")]
         if ok:
             best = max(ok, key=lambda k: table[k]["img_per_s"])
+            gfam = table[best].get("gemm_family")
+            roof = None
+            if gfam:
+                tr, tr_note = pmc_traffic(args, "" if best == "bf16" else "_" + best)
+                roof = {"kernel": "the same persistent 256x256 MFMA GEMM family as the headline, in this mode's operand type "
+                                  "(IEEE half on v_mfma_f32_16x16x32_f16 for fp16): QKV + out_proj + c_fc/GELU + c_proj launches",
+                        "bound": "mfma", "achieved": gfam["achieved"], "peak": gfam["peak"], "unit": "TFLOP/s", "frac": gfam["frac"],
+                        "avg_launch_us": gfam["avg_launch_us"], "flops_per_launch": gfam.get("flops_per_launch"),
+                        "traffic": tr, "traffic_note": tr_note}
             result["parity_mode"] = {"precision": best, "img_per_s": table[best]["img_per_s"],
                                      "encoder_mfma_frac": table[best]["encoder_mfma_frac"],
                                      "img_per_s_default_path": table[best].get("img_per_s_default_path"),
                                      "full_forward_ms": table[best].get("full_forward_ms"), "train_step_ms": table[best].get("train_step_ms"),
-                                     "gemm_family": table[best].get("gemm_family"), "kernels": table[best].pop("kernels", None),
+                                     "logits_per_sec": (round(args.batch * args.classes / (table[best]["full_forward_ms"] * 1e-3), 1)
+                                                        if table[best].get("full_forward_ms") else None),
+                                     "roofline": roof, "kernels": table[best].pop("kernels", None),
                                      "logits_rel_max_vs_cpu_oracle": table[best]["logits_rel_max_vs_cpu_oracle"],
                                      "logits_rel_l2_vs_cpu_oracle": table[best]["logits_rel_l2_vs_cpu_oracle"],
+                                     "logits_err_over_top2_margin": table[best].get("logits_err_over_top2_margin"),
                                      "note": "fastest precision whose FullModel logits are within BASELINE.json's 1e-3 of the CPU fp32 oracle "
-                                             f"(first {n_ref} images, {args.classes} classes); the headline `value` is the bf16 mode BASELINE configs[1] names"}
+                                             f"(first {n_ref} images, {args.classes} classes, the seeded prompts); the headline `value` is the bf16 mode "
+                                             "BASELINE configs[1] names.  full_forward_ms / train_step_ms: library defaults (CLS-only last image block)"}
+    if rank == 0 and world == 1 and not args.no_configs4 and (args.model, args.precision) == ("ViT-B-16", "bf16"):
+        result["configs4"] = configs4_leg(dev, events)
+        print(f"[bench] configs4 done at {time.perf_counter() - t_start:.1f}s", file=sys.stderr, flush=True)
     if world > 1:
         dist.barrier()
 

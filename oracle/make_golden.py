@@ -227,6 +227,35 @@ def g_fullmodel_b16_c65(ref):
         print(f"  {semantics}: {time.time() - t0:.0f}s")
 
 
+def g_hf_clip_vitb16(ref):
+    """An INDEPENDENT implementation at BASELINE's real dimensions: HF `transformers` CLIP built from a config at ViT-B/16
+    dims, carrying the seeded weights (oracle/hf_harness.py).  Its image embeddings, its encode_text features and its raw text
+    encoder on FullModel-style sequences ([16 context rows | token_embedding(zero-padded ids)], no position / mask /
+    ln_final: reference models/model_wrapper.py:58,72) are what the HIP towers are held to in tests/test_gpu_hf.py --
+    outputs of code that shares nothing with oracle/clip_ref.py."""
+    from oracle import hf_harness
+
+    cfg = clip_ref.CONFIGS["ViT-B-16"]
+    sd = synth.make_state_dict(cfg, seed=2)
+    t0 = time.time()
+    model = hf_harness.build_hf_clip(cfg, sd)
+    n, P, KEEP, B = 6, 16, 3, 4
+    names = class_list(65)[:n]
+    table = token_table(class_list(65), cfg)
+    tokens = torch.cat([table[f"a photo of a {c}"] for c in names], 0)        # [6, 77]
+    ctx = synth.make_prompts(65, P, cfg, seed=1)[0][:n]
+    prompts = torch.cat([ctx, sd["token_embedding.weight"][tokens]], dim=1)   # [6, 93, 512]
+    images = synth.make_images(B, cfg, 0)
+    img = hf_harness.image_features(model, images)
+    txt = hf_harness.text_features(model, tokens)
+    hidden, probs = hf_harness.raw_text_transformer(model, prompts)
+    print(f"  HF transformers {__import__('transformers').__version__}: {time.time() - t0:.0f}s")
+    _save("hf_clip_vitb16", seed_weights=2, seed_images=0, seed_context=1, batch=B, prompt_len=P, token_ids=tokens,
+          transformers_version=np.array(__import__("transformers").__version__),
+          image_embeddings=img, text_features=txt, raw_hidden=hidden[:KEEP], raw_hidden_last=hidden[:, -1],
+          raw_attn_mean=probs[:KEEP].mean(1), raw_probs_rows=probs[:KEEP, :, :4])
+
+
 def g_image_tower_l14(ref):
     """BASELINE.json configs[4] image side: the full-depth (24-block) ViT-L/14@336 tower at batch 2, fp32 and with the
     GEMM operands rounded to MXFP8 at the kernels' rounding points (regression pins of oracle/clip_ref.py: parity
@@ -333,7 +362,8 @@ def g_eval_metrics(ref):
 ALL = {"attribution_monitor": g_attribution_monitor, "prompt_adjustor": g_prompt_adjustor,
        "fullmodel_tiny": g_fullmodel_tiny, "block_real_dims": g_block_real_dims, "image_tower": g_image_tower,
        "fullmodel_b32": g_fullmodel_b32, "fullmodel_b16_c65": g_fullmodel_b16_c65, "image_tower_l14": g_image_tower_l14,
-       "fullmodel_l14": g_fullmodel_l14, "checkpoint": g_checkpoint, "eval_metrics": g_eval_metrics}
+       "fullmodel_l14": g_fullmodel_l14, "checkpoint": g_checkpoint, "eval_metrics": g_eval_metrics,
+       "hf_clip_vitb16": g_hf_clip_vitb16}
 
 
 def main():

@@ -171,27 +171,35 @@ class FullModel(nn.Module):
             return False
 
     # ---- image side ----------------------------------------------------------------------------
-    def _image_features_begin(self, images: torch.Tensor):
-        """Launch `encode_image` (reference model_wrapper.py:40-41); returns (features, stream to join)."""
+    def _image_features_begin(self, images: torch.Tensor, labels=None):
+        """Launch `encode_image` (reference model_wrapper.py:40-41) and, in the data-parallel form, the one exchange step
+        behind it; returns (features, labels, stream to join).  With `overlap_towers` both run on a second HIP stream: the
+        image tower beside the text tower's small grids, and the all-gather of the embeddings (RCCL over xGMI, 512 KiB per
+        rank) beside whatever the replicated text tower still has to do -- the main stream only waits for it at the logits."""
         vision = self.clip._vision
         if not (self.overlap_towers and images.is_cuda):
-            return vision.encode_image(images, normalize=True), None
+            feat = vision.encode_image(images, normalize=True)
+            feat, labels = self._gather(feat, labels)
+            return feat, labels, None
         dev = images.device
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=dev)
         side = self._side_stream
-        side.wait_stream(torch.cuda.current_stream(dev))  # the images were produced on the caller's stream
+        side.wait_stream(torch.cuda.current_stream(dev))  # the images (and labels) were produced on the caller's stream
         with torch.cuda.stream(side):
             feat = vision.encode_image(images, normalize=True)
-        return feat, side
+            feat, labels = self._gather(feat, labels)
+        return feat, labels, side
 
     @staticmethod
-    def _image_features_end(feat: torch.Tensor, side) -> torch.Tensor:
+    def _image_features_end(feat: torch.Tensor, labels, side):
         if side is not None:
             main = torch.cuda.current_stream(feat.device)
             main.wait_stream(side)
             feat.record_stream(main)
-        return feat
+            if labels is not None and labels.is_cuda:
+                labels.record_stream(main)
+        return feat, labels
 
     # ---- text side -----------------------------------------------------------------------------
     def _text_cache_key(self):
@@ -275,7 +283,7 @@ class FullModel(nn.Module):
         pl, clip = self.prompt_learner, self.clip
         with FullModel._ForwardGemms(clip):  # (the backward, later, runs with the K-split on again)
             with torch.no_grad():
-                image_feat, side = self._image_features_begin(images)
+                image_feat, labels, side = self._image_features_begin(images, labels)
                 ctx_c, tok = pl.stacked_context().detach(), pl.stacked_tokens()
                 run = self._tail_run()
                 clip.reset()
@@ -288,8 +296,7 @@ class FullModel(nn.Module):
             adjusted = torch.cat([self.prompt_adjustor(ctx, attribution), tok], dim=1)
             text_feat = _TextTowerFn.apply(adjusted, clip, run)
         with torch.no_grad():
-            image_feat = self._image_features_end(image_feat, side)
-            image_feat, labels = self._gather(image_feat, labels)
+            image_feat, labels = self._image_features_end(image_feat, labels, side)
         logits = _LogitsFn.apply(image_feat, text_feat, self.logit_scale)
         self.last_attribution = attribution
         outputs = {"logits": logits}
@@ -330,10 +337,9 @@ class FullModel(nn.Module):
                 labels = None if labels is None else labels.to(logits.device)
             else:
                 with FullModel._ForwardGemms(self.clip):
-                    image_feat, side = self._image_features_begin(images)                 # model_wrapper.py:40-41
+                    image_feat, labels, side = self._image_features_begin(images, labels)  # model_wrapper.py:40-41
                     text_feat = self.text_features()
-                image_feat = self._image_features_end(image_feat, side)
-                image_feat, labels = self._gather(image_feat, labels)
+                image_feat, labels = self._image_features_end(image_feat, labels, side)
                 logits = engine.logits(image_feat, text_feat, float(self.logit_scale.exp()))  # :79,83
             outputs = {"logits": logits}
             if labels is not None:

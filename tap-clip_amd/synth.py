@@ -114,6 +114,28 @@ def make_state_dict(cfg: ClipDims, seed: int = 2, vision: bool = True, text: boo
     return sd
 
 
+def make_state_dict_device(cfg: ClipDims, seed: int = 2, device="cuda", vision: bool = True, text: bool = True) -> Dict[str, torch.Tensor]:
+    """The same keys, shapes and scales as `make_state_dict`, drawn by torch's generator ON `device`: for throughput legs
+    that need a large model quickly and compare nothing with a golden (ViT-L/14@336: 428 M parameters are 45 s of the
+    host generator, 0.3 s here).  NOT the weights the goldens were made with."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    global normal
+    real = normal
+    try:  # run the host layout with a stand-in generator that records (shape, std, mean) only
+        normal = lambda shape, seed_, key, std=1.0, mean=0.0: ("spec", tuple(shape), float(std), float(mean))
+        host = make_state_dict(cfg, seed, vision, text)
+    finally:
+        normal = real
+    out = {}
+    for k, v in host.items():
+        if isinstance(v, tuple) and v and v[0] == "spec":
+            _, shape, std, mean = v
+            out[k] = torch.randn(shape, generator=g, device=device, dtype=torch.float32) * std + mean
+        else:
+            out[k] = v.to(device)
+    return out
+
+
 def make_images(batch: int, cfg: ClipDims, seed: int = 0) -> torch.Tensor:
     """[B,3,S,S] fp32 ~ N(0,1): stands in for CLIP-normalised pixels."""
     return normal([batch, 3, cfg.image_size, cfg.image_size], seed, "images")

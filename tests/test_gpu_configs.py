@@ -451,6 +451,19 @@ def test_bench_spawns_its_ranks_at_the_configs3_shape(tmp_path):
     assert res["config"]["parallelism"] == "dp4" and res["scaling"] == "weak" and res["dtype"] == "bf16"
     assert "gloo" in res["config"]["collective"] and "REHEARSAL" in res["config"]["collective"]
     assert res["value"] > 0 and abs(res["value"] - 1024 * res["steps"] / (res["ms_per_step"] * 1e-3 * res["steps"])) < 1e-3 * res["value"]
+    # what the first real multi-GPU run will be read by: ranks seen, each rank's device and step times,
+    # the exchange step's own duration, and the second metric measured over the whole job
+    rk = res["ranks"]
+    assert rk["rccl_ranks_seen"] == 4 and rk["backend"] == "gloo" and len(rk["per_rank"]) == 4
+    assert sorted(r_["rank"] for r_ in rk["per_rank"]) == [0, 1, 2, 3]
+    for r_ in rk["per_rank"]:
+        assert r_["device"].startswith("cuda") and 0 < r_["step_ms"]["min"] <= r_["step_ms"]["median"] <= r_["step_ms"]["max"]
+        assert r_["allgather_us"]["median"] > 0
+    ff = res["full_forward"]
+    assert "4 ranks" in ff["workload"] and ff["cls_only_last_block"] is False and ff["default_path"]["cls_only_last_block"] is True
+    assert abs(res["logits_per_sec"] - 1024 * 65 / (ff["ms_per_forward"] * 1e-3)) < 1e-3 * res["logits_per_sec"]
+    assert ff["text_rows_per_sequence"] == {**ff["text_rows_per_sequence"], "input": 93, "computed": 24}
+    assert res["train_step"]["ms_per_step"] > ff["default_path"]["ms_per_forward"]
     got = torch.from_numpy(np.load(out))
     assert got.shape == (1024, 65) and bool(torch.isfinite(got).all())
     # the same model in this process (what bench.py builds: seeds 2 / 1, bf16), one rank's images at a time

@@ -117,53 +117,12 @@ def test_fullmodel_vitb32_cfg1(semantics):
 def test_towers_match_hf_transformers_clip():
     """Independent second implementation of the tower arithmetic: HF `transformers` CLIP built from a
     config (no hub access), weights copied from a seeded open_clip-layout state dict."""
-    transformers = pytest.importorskip("transformers")
+    pytest.importorskip("transformers")
+    from oracle import hf_harness
+
     cfg = clip_ref.CONFIGS["tiny"]
     sd = synth.make_state_dict(cfg, seed=4)
-    v, t = cfg.vision, cfg.text
-    hf_cfg = transformers.CLIPConfig(
-        vision_config=dict(hidden_size=v.width, intermediate_size=v.mlp, num_hidden_layers=v.layers,
-                           num_attention_heads=v.heads, image_size=cfg.image_size, patch_size=cfg.patch,
-                           hidden_act="gelu", projection_dim=cfg.embed_dim, attn_implementation="eager"),
-        text_config=dict(hidden_size=t.width, intermediate_size=t.mlp, num_hidden_layers=t.layers,
-                         num_attention_heads=t.heads, vocab_size=cfg.vocab, max_position_embeddings=cfg.ctx,
-                         hidden_act="gelu", projection_dim=cfg.embed_dim, eos_token_id=cfg.vocab - 1,
-                         attn_implementation="eager"),
-        projection_dim=cfg.embed_dim)
-    model = transformers.CLIPModel(hf_cfg).eval()
-    hsd = model.state_dict()
-
-    def put(k, val):
-        assert hsd[k].shape == val.shape, (k, hsd[k].shape, val.shape)
-        hsd[k] = val.clone()
-
-    def tower(src, dst, layers, d):
-        for i in range(layers):
-            s, o = f"{src}resblocks.{i}.", f"{dst}.encoder.layers.{i}."
-            w, b = sd[s + "attn.in_proj_weight"], sd[s + "attn.in_proj_bias"]
-            for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):
-                put(o + f"self_attn.{nm}.weight", w[j * d:(j + 1) * d])
-                put(o + f"self_attn.{nm}.bias", b[j * d:(j + 1) * d])
-            put(o + "self_attn.out_proj.weight", sd[s + "attn.out_proj.weight"])
-            put(o + "self_attn.out_proj.bias", sd[s + "attn.out_proj.bias"])
-            for a, bb in (("ln_1", "layer_norm1"), ("ln_2", "layer_norm2")):
-                put(o + bb + ".weight", sd[s + a + ".weight"]); put(o + bb + ".bias", sd[s + a + ".bias"])
-            for a, bb in (("c_fc", "fc1"), ("c_proj", "fc2")):
-                put(o + f"mlp.{bb}.weight", sd[s + f"mlp.{a}.weight"]); put(o + f"mlp.{bb}.bias", sd[s + f"mlp.{a}.bias"])
-
-    tower("visual.transformer.", "vision_model", v.layers, v.width)
-    tower("transformer.", "text_model", t.layers, t.width)
-    put("vision_model.embeddings.patch_embedding.weight", sd["visual.conv1.weight"])
-    put("vision_model.embeddings.class_embedding", sd["visual.class_embedding"])
-    put("vision_model.embeddings.position_embedding.weight", sd["visual.positional_embedding"])
-    put("vision_model.pre_layrnorm.weight", sd["visual.ln_pre.weight"]); put("vision_model.pre_layrnorm.bias", sd["visual.ln_pre.bias"])
-    put("vision_model.post_layernorm.weight", sd["visual.ln_post.weight"]); put("vision_model.post_layernorm.bias", sd["visual.ln_post.bias"])
-    put("visual_projection.weight", sd["visual.proj"].t())
-    put("text_model.embeddings.token_embedding.weight", sd["token_embedding.weight"])
-    put("text_model.embeddings.position_embedding.weight", sd["positional_embedding"])
-    put("text_model.final_layer_norm.weight", sd["ln_final.weight"]); put("text_model.final_layer_norm.bias", sd["ln_final.bias"])
-    put("text_projection.weight", sd["text_projection"].t())
-    model.load_state_dict(hsd, strict=True)
+    model = hf_harness.build_hf_clip(cfg, sd)
 
     images = synth.make_images(3, cfg, 9)
     tokens = torch.zeros(4, cfg.ctx, dtype=torch.long)
@@ -173,14 +132,40 @@ def test_towers_match_hf_transformers_clip():
         tokens[i, 1:1 + L] = synth.integers([L], 3, f"hf.{i}", cfg.vocab - 3) + 1
         tokens[i, 1 + L] = cfg.vocab - 1
     with torch.no_grad():
-        img_hf = model.get_image_features(pixel_values=images)
-        txt_hf = model.get_text_features(input_ids=tokens)
-        img_hf = getattr(img_hf, "pooler_output", img_hf)
-        txt_hf = getattr(txt_hf, "pooler_output", txt_hf)
+        img_hf = hf_harness.image_features(model, images)
+        txt_hf = hf_harness.text_features(model, tokens)
         img = clip_ref.encode_image(images, sd, cfg)
         txt = clip_ref.encode_text(tokens, sd, cfg)
+        x = torch.cat([synth.normal([3, 5, cfg.text.width], 6, "hf.ctx"), sd["token_embedding.weight"][tokens[:3]]], dim=1)
+        hid_hf, probs_hf = hf_harness.raw_text_transformer(model, x)   # the transformer as FullModel drives it: no pos / mask / ln_final
+        hid, probs, _ = clip_ref.text_transformer_raw(x, sd, cfg, want_probs=True)
     assert rel_max(img, img_hf) < 1e-5
     assert rel_max(txt, txt_hf) < 1e-5
+    assert rel_max(hid, hid_hf) < 1e-5 and rel_max(probs, probs_hf) < 1e-5
+
+
+def test_towers_match_hf_transformers_clip_at_vitb16_dims():
+    """The same cross-check at BASELINE's real dimensions, against the outputs HF's CLIP produced for the seeded ViT-B/16
+    weights (tests/golden/hf_clip_vitb16.npz, written by oracle/make_golden.py::g_hf_clip_vitb16): image embeddings,
+    encode_text features, and the raw text transformer (hidden rows, last-layer probabilities) on [16 context | zero-padded
+    prompt] sequences.  The GPU suite holds the HIP towers to 1e-3 against the same file (tests/test_gpu_hf.py)."""
+    g = golden("hf_clip_vitb16")
+    cfg = clip_ref.CONFIGS["ViT-B-16"]
+    sd = synth.make_state_dict(cfg, seed=int(g["seed_weights"]))
+    images = synth.make_images(int(g["batch"]), cfg, int(g["seed_images"]))
+    tokens = torch.from_numpy(g["token_ids"])
+    n = tokens.shape[0]
+    ctx = synth.make_prompts(65, int(g["prompt_len"]), cfg, seed=int(g["seed_context"]))[0][:n]
+    prompts = torch.cat([ctx, sd["token_embedding.weight"][tokens]], dim=1)
+    with torch.no_grad():
+        assert rel_max(clip_ref.encode_image(images, sd, cfg), torch.from_numpy(g["image_embeddings"])) < 1e-5
+        assert rel_max(clip_ref.encode_text(tokens, sd, cfg), torch.from_numpy(g["text_features"])) < 1e-5
+        hid, probs, _ = clip_ref.text_transformer_raw(prompts, sd, cfg, want_probs=True)
+    k = g["raw_hidden"].shape[0]
+    assert rel_max(hid[:k], torch.from_numpy(g["raw_hidden"])) < 1e-5
+    assert rel_max(hid[:, -1], torch.from_numpy(g["raw_hidden_last"])) < 1e-5
+    assert rel_max(probs[:k].mean(1), torch.from_numpy(g["raw_attn_mean"])) < 1e-5
+    assert rel_max(probs[:k, :, :4], torch.from_numpy(g["raw_probs_rows"])) < 1e-5
 
 
 def test_emulated_bf16_oracle_is_close_to_fp32():
