@@ -286,8 +286,12 @@ void tapclip_comm_destroy(tapclip_comm_t* comm);
  * (open_clip pools token 0 before ln_post / proj; reference call site models/clip_wrapper.py:46-47), so in the LAST block
  * every other row's query, attention output, out_proj and MLP are dead work -- the reference computes them and throws
  * them away.  With the flag on, the last block computes K and V for every token and the rest for the CLS rows only
- * (same results to rounding: the CLS row's softmax and P.V run in fp32 there; in the fp8 precision the pooled rows' last block
- * runs on 16-bit copies of that block's weights).  0 = compute every row of every block
+ * (16-bit and split modes: the same results to rounding -- the CLS row's softmax and P.V run in fp32 there; measured against
+ * the full computation 3.6e-4 in bf16, whose own rounding is 2.2e-3, 4.4e-5 in fp16, 6e-7 in bf16x3.  fp8 precision: NOT
+ * the same pipeline -- the pooled rows' last block runs on 16-bit copies of that block's weights (14-25 MB per tower, made at
+ * load time unless TAPCLIP_PRUNE_LAST=0 is in the environment) instead of MXFP8, so those rows see one block less of MXFP8
+ * rounding: 9.6e-3 (ViT-B/16) / 6.5e-3 (ViT-L/14@336) from the all-MXFP8 computation, test bound 3e-2; parity of the fp8 mode
+ * is unpinned either way, the reference has no fp8).  0 = compute every row of every block
  * (what bench.py's headline `value` times: the full 35.127 GFLOP per ViT-B/16 image of SURVEY.md section 8d). */
 #define TAPCLIP_FLAG_PRUNE_LAST_BLOCK 1
 /* TAPCLIP_FLAG_KSPLIT (both towers, default 1): when a GEMM launch ends in a partial round of tiles (c_proj at ViT-B/16,
@@ -307,8 +311,9 @@ int tapclip_tower_get_flag(const tapclip_tower_t* tower, int32_t flag, int32_t* 
  * When enabled, tapclip_encode_image records events around each kernel family;
  * tapclip_profile_read (after a stream sync) returns accumulated ms and launch counts.
  * slots: 0 patch-embed, 1 layernorm, 2 gemm_qkv, 3 attention, 4 gemm_out_proj,
- *        5 gemm_fc_gelu, 6 gemm_proj, 7 pool_proj. */
-#define TAPCLIP_PROFILE_SLOTS 8
+ *        5 gemm_fc_gelu, 6 gemm_proj, 7 pool_proj (pool + ln_post + proj + L2 norm), 8 pooled_tail (the CLS rows' Q,
+ *        attention, out_proj, LN2 and MLP of the last block when TAPCLIP_FLAG_PRUNE_LAST_BLOCK is on). */
+#define TAPCLIP_PROFILE_SLOTS 9
 int tapclip_profile_enable(tapclip_tower_t* tower, int32_t on);
 int tapclip_profile_read(tapclip_tower_t* tower, float* ms_out, int64_t* launches_out);
 

@@ -75,7 +75,7 @@ PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp8": PREC_FP8, "fp16":
 FLAG_PRUNE_LAST_BLOCK = 1
 FLAG_KSPLIT = 2  # K-split of partial GEMM rounds over idle CUs: latency (1, default) against CU-time (0)
 PROFILE_SLOTS = ("patch_embed", "layernorm", "gemm_qkv", "attention", "gemm_out_proj", "gemm_fc_gelu",
-                 "gemm_proj", "pool_proj")
+                 "gemm_proj", "pool_proj", "pooled_tail")
 
 EINVAL, ENOMEM, EHIP, ESTATE, EWORKSPACE = -1, -2, -3, -4, -5
 

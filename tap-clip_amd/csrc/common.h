@@ -23,6 +23,26 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#if defined(TAPCLIP_TU_NO_PK_F32) && defined(__HIP_DEVICE_COMPILE__)
+// threadIdx / blockIdx / blockDim / gridDim are device-library accessors compiled WITH packed-fp32 ops: they do not
+// inline into a no-packed-fp32 function (a callee is inlined only into callers that have all of its target features) and
+// would become real calls.  Inside such a translation unit they are the hardware builtins instead.
+namespace tapclip {
+struct dim3u { unsigned x, y, z; };
+__device__ __forceinline__ dim3u tid3() { return {__builtin_amdgcn_workitem_id_x(), __builtin_amdgcn_workitem_id_y(), __builtin_amdgcn_workitem_id_z()}; }
+__device__ __forceinline__ dim3u bid3() { return {__builtin_amdgcn_workgroup_id_x(), __builtin_amdgcn_workgroup_id_y(), __builtin_amdgcn_workgroup_id_z()}; }
+__device__ __forceinline__ dim3u bdim3() { return {__builtin_amdgcn_workgroup_size_x(), __builtin_amdgcn_workgroup_size_y(), __builtin_amdgcn_workgroup_size_z()}; }
+__device__ __forceinline__ dim3u gdim3() {
+  return {__builtin_amdgcn_grid_size_x() / __builtin_amdgcn_workgroup_size_x(), __builtin_amdgcn_grid_size_y() / __builtin_amdgcn_workgroup_size_y(),
+          __builtin_amdgcn_grid_size_z() / __builtin_amdgcn_workgroup_size_z()};
+}
+}  // namespace tapclip
+#define threadIdx (::tapclip::tid3())
+#define blockIdx (::tapclip::bid3())
+#define blockDim (::tapclip::bdim3())
+#define gridDim (::tapclip::gdim3())
+#endif
+
 namespace tapclip {
 
 // The 16-bit operand type.  Every kernel handles it as raw 16-bit patterns (`bf16_t`) through the helpers below,

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
           for (int e = 0; e < 4; ++e) v[e] = SPLIT ? gelu_erf(v[e]) : gelu_fast16(v[e]);  // see common.h
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_quick(v[e]);
+          for (int e = 0; e < 4; ++e) v[e] = SPLIT ? gelu_quick(v[e]) : gelu_quick_fast(v[e]);
         }
       }
       if (EPI == EPI_GELU_BWD_BF16) {
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void splitk_fixup_kernel(GemmArgs g, int n_til
     v += *reinterpret_cast<const f32x4_t*>(g.split_ws + (size_t)(t * g.split_parts + p) * (BM * BN) + rr * BN + c4 * 4);
   if (EPI == EPI_BIAS_GELU_BF16) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = g.act == 0 ? (SPLIT ? gelu_erf(v[e]) : gelu_fast16(v[e])) : gelu_quick(v[e]);  // (as the GEMM's own epilogue)
+    for (int e = 0; e < 4; ++e) v[e] = g.act == 0 ? (SPLIT ? gelu_erf(v[e]) : gelu_fast16(v[e])) : (SPLIT ? gelu_quick(v[e]) : gelu_quick_fast(v[e]));  // (as the GEMM's own epilogue, per precision)
   }
   if (EPI == EPI_BIAS_F32) {  // (the dX GEMMs of the prompt-tuning backward: fp32 gradients)
     *reinterpret_cast<f32x4_t*>(g.out_f32 + m * g.ldo + n) = v;

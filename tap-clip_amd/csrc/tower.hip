@@ -200,7 +200,8 @@ const Roctx& roctx() {
   return r;
 }
 const char* const kSlotNames[TAPCLIP_PROFILE_SLOTS] = {"tapclip:patch_embed", "tapclip:layernorm", "tapclip:gemm_qkv", "tapclip:attention",
-                                                       "tapclip:gemm_out_proj", "tapclip:gemm_fc_gelu", "tapclip:gemm_proj", "tapclip:pool_proj"};
+                                                       "tapclip:gemm_out_proj", "tapclip:gemm_fc_gelu", "tapclip:gemm_proj", "tapclip:pool_proj",
+                                                       "tapclip:pooled_tail"};
 
 struct ProfScope {
   tapclip_tower* t;
@@ -546,7 +547,7 @@ int run_last_block_pooled(tapclip_tower* t, float* x, int64_t n_seq, int tokens,
     if ((rc = gemm(t, 2, EPI_BIAS_BF16, w.xn_hi, w.xn_lo, D, wkv, L.bqkv + D, M, 2 * D, D, w.qkv_hi + D, w.qkv_lo ? w.qkv_lo + D : nullptr,
                    nullptr, 3 * D, s))) return rc;
   }
-  ProfScope ps(t, 7, s);  // everything on the n_seq CLS rows is accounted to the pool / project slot
+  ProfScope ps(t, 8, s);  // everything on the n_seq CLS rows: its own slot ("pooled_tail"); slot 7 stays the pool / ln_post / proj kernel
   // fp8 precision: the block's LayerNorm wrote MXFP8 rows only, and the residual stream is 16-bit (w.x16): the CLS rows are
   // gathered to fp32 first and normalised again in 16 bits for the (16-bit) skinny GEMMs of the pooled tail
   const bf16_t* qa_hi = w.xn_hi;
@@ -559,7 +560,6 @@ int run_last_block_pooled(tapclip_tower* t, float* x, int64_t n_seq, int tokens,
     qa_ld = D;
   }
   // Q of the CLS rows: A = row b * tokens of xn (row stride tokens * D)
-  GemmArgs g;
   auto small_gemm = [&](int epi, const bf16_t* ah, const bf16_t* al, int64_t lda, const Packed& wt, const float* bias, int N, int K, bf16_t* oh,
                         bf16_t* ol) {
     GemmArgs a;
@@ -569,7 +569,7 @@ int run_last_block_pooled(tapclip_tower* t, float* x, int64_t n_seq, int tokens,
     a.M = n_seq; a.N = N; a.K = K;
     a.out_hi = oh; a.out_lo = ol; a.out_f32 = nullptr; a.ldo = N;
     a.add_table = nullptr; a.rows_per_group = 0; a.act = t->cfg.act;
-    a.split_ws = t->split_ws;
+    a.split_ws = nullptr;  // (the tiled fallback below runs WITHOUT the K-split of partial rounds: its split is chosen from the tile count, i.e. from the batch)
     // a few hundred rows: the split-K skinny kernel (gemm_skinny.hip), for EVERY batch size -- its K slices depend on (N, K)
     // only, so a pooled row sums in the same order whatever its batch (bitwise batch invariance).  Its fp32 slabs live in
     // the handle's K-split scratch (allocated here when no large GEMM has done it yet: small batches).
@@ -578,13 +578,14 @@ int run_last_block_pooled(tapclip_tower* t, float* x, int64_t n_seq, int tokens,
         void* p = nullptr;
         if (dev_alloc(t, gemm256_split_ws_bytes(), &p) != TAPCLIP_OK) return hipErrorOutOfMemory;
         t->split_ws = static_cast<float*>(p);
-        a.split_ws = t->split_ws;
       }
       return launch_gemm_skinny(a, epi, t->split, t->split_ws, gemm256_split_ws_bytes(), s);
     }
+    // shapes the skinny kernel does not take (more than 1024 rows, N or K off its tiling): the tiled kernels, whole tiles only
+    // -- still a fixed summation order per row, but which kernel runs now depends on the batch, so the bitwise batch
+    // invariance of the pooled rows is a property of the skinny path only
     return launch_gemm(a, epi, t->split, s);
   };
-  (void)g;
   HIP_TRY(small_gemm(EPI_BIAS_BF16, qa_hi, qa_lo, qa_ld, L.wqkv, L.bqkv, D, D, q_hi, q_lo));
   HIP_TRY(launch_attention_pooled(q_hi, q_lo, w.qkv_hi, w.qkv_lo, ao_hi, ao_lo, (int)n_seq, tokens, H, D, t->split, s));
   HIP_TRY(small_gemm(EPI_BIAS_BF16, ao_hi, ao_lo, D, L.wo, L.bo, D, D, a_hi, a_lo));
@@ -838,7 +839,7 @@ int tapclip_tower_load_weight(tapclip_tower_t* t, const char* key_c, const float
       rc = own_packed_mx8(t, src, rows, (int)cols, qkv ? D : 0, qkv ? qscale : 1.f, qkv ? &L.qqkv : fc ? &L.qfc : pr ? &L.qpr : &L.qo, s);
       // the LAST block also keeps 16-bit copies: its CLS-only tail (run_last_block_pooled) runs the M = batch GEMMs of
       // the pooled rows on the 16-bit skinny kernel (14 - 25 MB per tower; those rows then see no MXFP8 rounding at all)
-      if (!rc && li == t->cfg.layers - 1)
+      if (!rc && li == t->cfg.layers - 1 && t->prune_last)  // (TAPCLIP_PRUNE_LAST=0 at creation: no pooled tail, no copies)
         rc = own_packed(t, src, rows, (int)cols, (int)cols, qkv ? D : 0, qkv ? qscale : 1.f, qkv ? &L.wqkv : fc ? &L.wfc : pr ? &L.wpr : &L.wo, s);
     }
     else if (sub == "attn.in_proj_weight") rc = mat(3 * D, D, &L.wqkv, &L.wqkv_t, D, qscale);
@@ -1454,7 +1455,13 @@ void tapclip_comm_destroy(tapclip_comm_t* comm) {
 int tapclip_tower_set_flag(tapclip_tower_t* t, int32_t flag, int32_t value) {
   if (!t) return fail(TAPCLIP_EINVAL, "null tower");
   switch (flag) {
-    case TAPCLIP_FLAG_PRUNE_LAST_BLOCK: t->prune_last = value != 0; return TAPCLIP_OK;
+    case TAPCLIP_FLAG_PRUNE_LAST_BLOCK:
+      // fp8 towers keep 16-bit copies of the last block's weights for the pooled rows; a tower created with
+      // TAPCLIP_PRUNE_LAST=0 in the environment did not make them
+      if (value != 0 && t->fp8 && !t->layers.empty() && t->layers.back().wqkv.hi == nullptr && !t->loaded.empty())
+        return fail(TAPCLIP_ESTATE, "this fp8 tower was created with TAPCLIP_PRUNE_LAST=0: it holds no 16-bit copy of the last block for the CLS-only path");
+      t->prune_last = value != 0;
+      return TAPCLIP_OK;
     case TAPCLIP_FLAG_KSPLIT: t->ksplit = value != 0; return TAPCLIP_OK;
     default: return fail(TAPCLIP_EINVAL, "unknown tower flag %d", flag);
   }

@@ -35,9 +35,56 @@ def _count(model, dataloader, device):
     return correct, total
 
 
+def _synced_batches(model, dataloader, device):
+    """The rank's batches, followed by empty ones until the rank with the most batches has run out (data-parallel
+    evaluation only: every iteration of the loop body issues collectives that all ranks must join)."""
+    import torch.distributed as dist
+
+    from ..dist import is_distributed
+
+    if not is_distributed():
+        yield from dataloader
+        return
+    cpu = dist.get_backend() == "gloo"
+
+    def agree_max(v: int) -> int:
+        t = torch.tensor([v], dtype=torch.int64, device="cpu" if cpu else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return int(t.item())
+
+    size = getattr(getattr(getattr(model, "clip", None), "cfg", None), "image_size", None)
+    shape = None if size is None else (3, size, size)
+
+    def empty():
+        if shape is None:
+            raise RuntimeError("a rank without a single batch cannot shape its empty batches: the model has no clip.cfg.image_size")
+        return torch.zeros((0,) + tuple(shape)), torch.zeros(0, dtype=torch.int64)
+
+    it = iter(dataloader)
+    if hasattr(dataloader, "__len__"):
+        longest = agree_max(len(dataloader))      # ONE collective for the whole loop
+        for _ in range(longest):
+            batch = next(it, None)
+            if batch is None:
+                batch = empty()
+            else:
+                shape = tuple(batch[0].shape[1:])
+            yield batch
+        return
+    while True:                                    # a loader without a length: one tiny collective per batch
+        batch = next(it, None)
+        if agree_max(0 if batch is None else 1) == 0:
+            return
+        if batch is None:
+            batch = empty()
+        else:
+            shape = tuple(batch[0].shape[1:])
+        yield batch
+
+
 def _count_loop(model, dataloader, device, gather):
     correct = total = None
-    for images, labels in dataloader:
+    for images, labels in (_synced_batches(model, dataloader, device) if gather else dataloader):
         images, labels = images.to(device), labels.to(device)
         logits = model(images)["logits"]
         n_cls = logits.shape[1]

@@ -380,6 +380,17 @@ with contextlib.redirect_stdout(io.StringIO()):
     acc_s = eval_metrics.evaluate_accuracy(m, [(images[lo:hi], labels[lo:hi])], "cuda:0")
     acc_f = eval_metrics.evaluate_accuracy(build(False).eval(), [(images, labels)], "cuda:0")
 assert acc_s == acc_f, (acc_s, acc_f)
+# unequal shards end to end (ADVICE r03): rank 0 holds 5 images in batches of 2 (2 + 2 + 1), rank 1 holds 3 in ONE batch of
+# 3 -- different batch counts AND different batch lengths; the loop must neither hang nor miscount, with a sized loader and
+# with a bare generator (no __len__)
+mine = [(images[0:2], labels[0:2]), (images[2:4], labels[2:4]), (images[4:5], labels[4:5])] if rank == 0 else [(images[5:8], labels[5:8])]
+with contextlib.redirect_stdout(io.StringIO()):
+    acc_u = eval_metrics.evaluate_accuracy(m, mine, "cuda:0")
+    acc_g = eval_metrics.evaluate_accuracy(m, (b for b in mine), "cuda:0")
+    per_u = eval_metrics.evaluate_per_class_accuracy(m, mine, "cuda:0", names)
+    per_f = eval_metrics.evaluate_per_class_accuracy(build(False).eval(), [(images, labels)], "cuda:0", names)
+assert acc_u == acc_f and acc_g == acc_f and per_u == per_f, (acc_u, acc_g, acc_f, per_u, per_f)
+assert m.ragged_batches is False
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok", rel(g_s, g_f))
 """
@@ -555,8 +566,9 @@ def test_pruned_last_block_equals_the_full_computation(eng, name, batch):
     the reference's pooling throws away (models/clip_wrapper.py:46-47).  Against the same tower computing every row of every
     block, in every precision that has the path: equal to the precision's own rounding (the pooled row's softmax and P.V
     run in fp32, the full kernel rounds P to 16 bits) -- bf16x3 to 1e-5, fp16 to 2e-4, bf16 to 1.5e-3 -- deterministic, and
-    independent of the batch the image sits in (ragged batch sizes included).  ("tiny" at batch 1100: more rows than the
-    skinny GEMM takes, so the pooled rows fall back to the tiled kernel; width 128, so the residual stream is fp32.)"""
+    independent of the batch the image sits in (ragged batch sizes included).  ("tiny" at batch 1100: more rows than one
+    skinny-GEMM launch takes -- they go through it in chunks of 1024, K slices depending on (N, K) only, so the pooled rows
+    stay on the skinny path; width 128, so the residual stream is fp32.)"""
     cfg = configs.get_config(name)
     sd = synth.make_state_dict(cfg, seed=2, text=False)
     images = synth.make_images(batch, cfg, 11).to(DEV)

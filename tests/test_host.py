@@ -69,6 +69,26 @@ assert torch.equal(all_gather_rows((labels[:cut] if rank == 0 else labels[cut:])
 mine = full[:2] if rank == 0 else full[:0]
 assert torch.equal(all_gather_rows(mine.clone(), ragged=True), full[:2])
 assert torch.equal(all_gather_rows(full[lo:hi].clone(), ragged=True), full)    # equal shards: same result as the plain path
+# the evaluation loop on shards with DIFFERENT numbers of batches (tap-clip_amd/utils/eval_metrics.py::_synced_batches): a stand-in
+# for the data-parallel FullModel -- its forward gathers the ranks' rows like FullModel(gather_images=True) does -- must count
+# the global totals on both ranks, with a sized loader and with a bare generator, instead of hanging in a collective
+import contextlib, io, types
+from tap_clip_amd.utils import eval_metrics
+class Stub:
+    gather_images, ragged_batches = True, False
+    clip = types.SimpleNamespace(cfg=types.SimpleNamespace(image_size=2))
+    def eval(self): return self
+    def __call__(self, images):
+        return {{"logits": all_gather_rows(images.flatten(1)[:, :5].contiguous(), ragged=self.ragged_batches)}}
+imgs = torch.randn(11, 3, 2, 2, generator=g); labs = torch.arange(11) % 5
+want = (imgs.flatten(1)[:, :5].argmax(1) == labs).float().mean().item() * 100
+shard = [(imgs[0:3], labs[0:3]), (imgs[3:6], labs[3:6]), (imgs[6:7], labs[6:7])] if rank == 0 else [(imgs[7:11], labs[7:11])]
+with contextlib.redirect_stdout(io.StringIO()):
+    a1 = eval_metrics.evaluate_accuracy(Stub(), shard, "cpu")
+    a2 = eval_metrics.evaluate_accuracy(Stub(), (b for b in shard), "cpu")
+    a3 = eval_metrics.evaluate_accuracy(Stub(), shard if rank == 0 else [], "cpu")      # a rank with no batch at all
+want3 = (imgs[:7].flatten(1)[:, :5].argmax(1) == labs[:7]).float().mean().item() * 100
+assert abs(a1 - want) < 1e-4 and abs(a2 - want) < 1e-4 and abs(a3 - want3) < 1e-4, (a1, a2, a3, want, want3)
 dist.barrier(); dist.destroy_process_group()
 print("ok", rank)
 """
