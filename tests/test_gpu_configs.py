@@ -515,10 +515,18 @@ def test_vit_l14_336_batch_128_properties(eng):
         assert a.shape == (128, cfg.embed_dim) and bool(torch.isfinite(a).all())
         assert torch.equal(a, b), f"{precision}: same input twice must be bit-identical"
         assert torch.allclose(a.norm(dim=-1), torch.ones(128, device=DEV), atol=1e-5)
-        small = tower.encode_image(big[:2].clone(), normalize=True)
         _report(f"ViT-L/14@336 batch 128 {precision}: golden rows in the big batch", a[:2].cpu(), ref)
         assert rel_l2(a[:2].cpu(), ref) < tol
-        assert rel_l2(a[:2].cpu(), small.cpu()) < 1e-6, precision  # (first row tiles: no K-split tail involved)
+        # the same two images alone (2 x 577 = 1 154 rows: since round 4 the persistent GEMM's shape too, where every tile of
+        # so small a launch is K-split over the idle CUs).  Without the K-split the rows sum in the big batch's order (its
+        # first row tiles are whole tiles); with it they differ by the mode's round-off, as documented for the tail split
+        tower.set_ksplit(False)
+        small = tower.encode_image(big[:2].clone(), normalize=True)
+        assert rel_l2(a[:2].cpu(), small.cpu()) < 1e-6, precision
+        tower.set_ksplit(True)
+        small = tower.encode_image(big[:2].clone(), normalize=True)
+        _report(f"ViT-L/14@336 {precision}: batch 2 (K-split tiles) against the same rows of batch 128", small.cpu(), a[:2].cpu())
+        assert rel_l2(a[:2].cpu(), small.cpu()) < {"fp8": 1e-6, "fp16": TOL, "bf16": TOL_TAIL_SPLIT}[precision], precision
         tower.close()
         del tower
         torch.cuda.empty_cache()
