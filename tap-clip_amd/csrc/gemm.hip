@@ -10,8 +10,8 @@
 // (bf16) / 16-byte (fp32) vector stores and vector bias loads in the epilogue.
 // LDS image: [128 rows][64 bf16] = 128-B rows, 16-B chunk index XOR (row & 7) so the ds_read_b128
 // fragment reads of 16 different rows at one k-chunk spread over 8 slots (guide T2).
-// bf16x3 (SPLIT): the K loop runs three segments (A_hi,W_hi), (A_lo,W_hi), (A_hi,W_lo) into the same
-// accumulators.
+// bf16x3 (SPLIT): every 64-deep k-slice is visited three times in turn -- (A_hi,W_hi), (A_lo,W_hi), (A_hi,W_lo) -- into the
+// same accumulators.
 #include <cstdlib>
 
 // (NOT built with TAPCLIP_TU_NO_PK_F32: measured in round 4, tools/ab_pk.sh -- the split-bf16 epilogues of this kernel carry
@@ -34,9 +34,9 @@ constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 #define TAPCLIP_STAGE_LOAD(KT_IDX)                                                              \
   {                                                                                             \
     int seg_ = 0, kk_ = (KT_IDX);                                                               \
-    if (SPLIT) {                                                                                \
-      seg_ = kk_ / KT1;                                                                         \
-      kk_ -= seg_ * KT1;                                                                        \
+    if (SPLIT) { /* the three products of one k-slice in turn, as gemm256.hip / gemm_lat.hip */ \
+      seg_ = kk_ % 3;                                                                           \
+      kk_ /= 3;                                                                                 \
     }                                                                                           \
     const bf16_t* Ap_ = (SPLIT && seg_ == 1) ? g.A_lo : g.A_hi;                                 \
     const bf16_t* Wp_ = (SPLIT && seg_ == 2) ? g.W_lo : g.W_hi;                                 \
@@ -236,6 +236,8 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
 
 hipError_t launch_gemm256(const GemmArgs& a, int epilogue, bool split, hipStream_t s);  // gemm256.hip
 bool gemm256_supports(const GemmArgs& a);
+hipError_t launch_gemm_lat(const GemmArgs& a, int epilogue, bool split, hipStream_t s);  // gemm_lat.hip
+bool gemm_lat_supports(const GemmArgs& a);
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, bool split, hipStream_t s) {
   if (a.M <= 0 || a.N % BN != 0 || a.K % BK != 0 || a.K <= 0) return hipErrorInvalidValue;
@@ -248,16 +250,24 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, bool split, hipStream_t 
     const char* e = getenv("TAPCLIP_GEMM_TILE");
     return e ? atoi(e) : 0;
   }();
-  // Round 4: with the tied padding rows merged the 65-class text pass is M = 65 x 24..26 = 1 560..1 690 rows.  Measured at
-  // M = 1 560 (tools/train_phases.py, text_features alone): bf16 2.30 ms on the persistent kernel against 4.53 ms on the
-  // register-staged one; split-bf16 5.79 against 4.92 ms (there the persistent kernel K-splits every tile and pays a fix-up
-  // per GEMM) -- hence 1 024 rows for one product, 2 048 for three.  TAPCLIP_GEMM256_MIN_M overrides both (experiments).
+  // Round 4: with the tied padding rows merged the 65-class text pass is M = 65 x 24..26 = 1 560..1 690 rows -- one partial
+  // round of tiles for either tiled kernel, i.e. a latency problem: below 2 048 rows the one-tile-per-CU LDS-DMA kernel of
+  // gemm_lat.hip runs (deep ring, tile shape per launch, the three split-bf16 products on ONE staging of the operands).
+  // Measured at M = 1 560 before it existed (tools/train_phases.py, text_features alone): bf16 2.30 ms on the persistent
+  // kernel against 4.53 ms on the register-staged one of this file; split-bf16 5.79 against 4.92 ms.
+  // TAPCLIP_GEMM_LAT=0 takes it out (A/B: then 1 024 rows for one product, 2 048 for three decide between the other two);
+  // TAPCLIP_GEMM256_MIN_M moves the persistent kernel's threshold (experiments).
+  static const bool use_lat = [] {
+    const char* e = getenv("TAPCLIP_GEMM_LAT");
+    return e == nullptr || atoi(e) != 0;
+  }();
   static const int64_t min_m_env = [] {
     const char* e = getenv("TAPCLIP_GEMM256_MIN_M");
     return e ? (int64_t)atoll(e) : (int64_t)0;
   }();
-  const int64_t min_m = min_m_env > 0 ? min_m_env : (split ? 2048 : 1024);
+  const int64_t min_m = min_m_env > 0 ? min_m_env : ((split || use_lat) ? 2048 : 1024);
   if (gemm256_supports(a) && (forced == 256 || (forced != 128 && a.M >= min_m))) return launch_gemm256(a, epilogue, split, s);
+  if (use_lat && forced != 128 && gemm_lat_supports(a)) return launch_gemm_lat(a, epilogue, split, s);
 #define TAPCLIP_GEMM_CASE(E)                                      \
   case E:                                                         \
     return split ? launch_t<E, true>(a, s) : launch_t<E, false>(a, s);

