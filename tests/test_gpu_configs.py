@@ -28,7 +28,7 @@ import tap_clip_amd  # noqa: F401
 from conftest import golden, rel_l2, rel_max
 from oracle import clip_ref
 from tap_clip_amd import configs, synth
-from test_gpu_parity import DEV, TOL, TOL_BF16, _build_full, _report
+from test_gpu_parity import DEV, TOL, TOL_BF16, TOL_TAIL_SPLIT, _build_full, _report
 
 pytestmark = pytest.mark.gpu
 
