@@ -99,6 +99,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 #ifndef TAPCLIP_GELU_TR
 #define TAPCLIP_GELU_TR 0
 #endif
+#ifndef TAPCLIP_GELU_FULL_LINES
+#define TAPCLIP_GELU_FULL_LINES 0  // (A/B: tools/Makefile gemm_bench_alt ALT_DEFS=-DTAPCLIP_GELU_FULL_LINES=1)
+#endif
 #ifndef TAPCLIP_EPI_EARLY_B
 #define TAPCLIP_EPI_EARLY_B 1  // group B's epilogue in the same phase as group A's (see the tile boundary below)
 #endif
@@ -363,6 +366,50 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
       if (EPI != EPI_BIAS_GELU_BF16 || g.act == 0) tr_body(std::integral_constant<int, 0>{});
       else if (g.act == 1) tr_body(std::integral_constant<int, 1>{});
       else tr_body(std::integral_constant<int, 2>{});
+      return;
+    }
+    if (PERM && TAPCLIP_GELU_FULL_LINES && BN == 256) {
+      // Full-line variant of the store below (round 4, VERDICT r03 "what's weak" 7: the direct fragment stores cover 16 rows
+      // x 64 B per instruction -- half lines -- and c_fc wrote 435 MB for its 310 MB output).  A wave's 64 columns are ONE
+      // 128-B line per row and lane (r, q) holds its chunks q (sub-tile pair 0) and 4 + q (pair 1).  Rows r and r ^ 8 trade
+      // one chunk each through a DPP rotate by 8 inside the 16-lane row: lanes r < 8 end up with chunk q of rows r and r + 8,
+      // lanes r >= 8 with chunk 4 + q of the same two rows, so each of the two store instructions of a 16-row block writes
+      // 8 rows x 128 B -- whole lines.  Same number of stores, 12 extra VALU ops per block.
+      auto body = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+        const bool upper = r >= 8;  // this lane keeps the chunks 4 + q
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          u32x4_t pk[2];
+#pragma unroll
+          for (int J = 0; J < 2; ++J) {
+            f32x4_t v0 = acc[2 * J][i], v1 = acc[2 * J + 1][i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v0[e] = ACT == 0 ? gelu_fast16(v0[e]) : ACT == 1 ? gelu_quick_fast(v0[e]) : v0[e];
+              v1[e] = ACT == 0 ? gelu_fast16(v1[e]) : ACT == 1 ? gelu_quick_fast(v1[e]) : v1[e];
+            }
+            pk[J][0] = pack_bf2(v0[0], v0[1]);
+            pk[J][1] = pack_bf2(v0[2], v0[3]);
+            pk[J][2] = pack_bf2(v1[0], v1[1]);
+            pk[J][3] = pack_bf2(v1[2], v1[3]);
+          }
+          // send the chunk this lane does not keep (pair 1 from the lower rows, pair 0 from the upper ones) to lane r ^ 8
+          u32x4_t got;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            got[e] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(upper ? pk[0][e] : pk[1][e]), 0x128 /* row_ror:8 */, 0xF, 0xF, false);
+          const u32x4_t keep = upper ? pk[1] : pk[0];
+          // lower lanes: (row r: own, row r + 8: received); upper lanes: (row r - 8: received, row r: own)
+          const int64_t mA = m0 + wm * 128 + i * 16 + (r & 7), mB = mA + 8;
+          bf16_t* col = g.out_hi + n0 + wn * (BN / 4) + 8 * q + (upper ? 32 : 0);
+          if (mA < g.M) st16_policy(reinterpret_cast<u32x4_t*>(col + mA * g.ldo), upper ? got : keep);
+          if (mB < g.M) st16_policy(reinterpret_cast<u32x4_t*>(col + mB * g.ldo), upper ? keep : got);
+        }
+      };
+      if (g.act == 0) body(std::integral_constant<int, 0>{});
+      else if (g.act == 1) body(std::integral_constant<int, 1>{});
+      else body(std::integral_constant<int, 2>{});
       return;
     }
     if (PERM) {

@@ -421,6 +421,30 @@ def test_fullmodel_tiny_vs_reference(semantics, precision):
     assert set(g["state_dict_keys"].tolist()) <= keys, sorted(set(g["state_dict_keys"].tolist()) - keys)[:5]
 
 
+def _oracle_context_grad(g, cfg_name, semantics, emulate):
+    """d loss / d context of FullModel's collapsed forward through the CPU oracle (torch autograd), with the operand rounding
+    of `emulate` at the kernels' rounding points; the attribution is a constant (reference clip_wrapper.py:36 detaches it)."""
+    import math
+    from oracle import full_model_ref
+
+    cfg = clip_ref.CONFIGS[cfg_name]
+    sd = synth.make_state_dict(configs.get_config(cfg_name), seed=int(g["seed_weights"]))
+    P = int(g["prompt_len"])
+    ctx = torch.from_numpy(g["context"]).clone().requires_grad_(True)
+    tok = sd["token_embedding.weight"][torch.from_numpy(g["token_ids"])]
+    images = synth.make_images(int(g["batch"]), configs.get_config(cfg_name), int(g["seed_images"]))
+    with torch.no_grad():
+        _, aux = full_model_ref.text_features(torch.cat([ctx.detach(), tok], 1), P, sd, cfg, semantics, emulate, return_aux=True)
+        img = clip_ref.encode_image(images, sd, cfg, emulate, normalize=True)
+    adjusted = torch.cat([full_model_ref.adjust_scale(ctx, aux["attribution"]), tok], dim=1)
+    hidden, _, _ = clip_ref.text_transformer_raw(adjusted, sd, cfg, emulate)
+    feat = hidden[:, -1, :] @ sd["text_projection"]
+    feat = feat / feat.norm(dim=-1, keepdim=True)
+    logits = math.exp(math.log(1 / 0.07)) * img @ feat.t()
+    torch.nn.functional.cross_entropy(logits, torch.from_numpy(g["labels"])).backward()
+    return ctx.grad.detach()
+
+
 @pytest.mark.parametrize("semantics", ["literal", "intended"])
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 def test_fullmodel_backward_vs_reference(semantics, precision):
@@ -436,8 +460,18 @@ def test_fullmodel_backward_vs_reference(semantics, precision):
     grad = torch.stack([model.prompt_learner.context_bank[c].grad for c in names], 0).cpu()
     ref = torch.from_numpy(g["context_grad"])
     _report(f"FullModel tiny {semantics} {precision} context grad", grad, ref)
-    tol = TOL if precision == "bf16x3" else 5e-2
+    if precision == "bf16x3":
+        tol = TOL
+    else:
+        # what bf16 operands cost these gradients, measured: torch autograd through the oracle with bf16 rounding at the
+        # kernels' rounding points (attribution a constant, as the reference's hook detaches it) against the reference's
+        # own gradients; the HIP backward rounds its gradient operands too and is held to 2x that (it was a chosen 5e-2)
+        e_grad = _oracle_context_grad(g, "tiny", semantics, "bf16")
+        assert rel_max(_oracle_context_grad(g, "tiny", semantics, None), ref) < 1e-4
+        tol = 2 * max(rel_max(e_grad, ref), rel_l2(e_grad, ref))
+        print(f"[parity] bf16 context-gradient floor x2 = {tol:.3e}; HIP {rel_max(grad, ref):.3e} / {rel_l2(grad, ref):.3e}")
     assert rel_max(grad, ref) < tol and rel_l2(grad, ref) < tol
+    tol = TOL if precision == "bf16x3" else TOL_BF16
     assert abs(float(model.logit_scale.grad) - float(g["logit_scale_grad"])) < tol * max(1.0, abs(float(g["logit_scale_grad"])))
     assert abs(float(out["loss"]) - float(g["loss"])) < tol * max(1.0, abs(float(g["loss"])))
     assert all(p.grad is None for p in model.clip.parameters())  # CLIP stays frozen
@@ -462,9 +496,23 @@ def test_text_backward_real_dims_vs_oracle_autograd(eng, precision):
     g_hidden = tower.pool_project_backward(hid, gfeat.to(DEV), normalize=True)
     gx = tower.backward(x.to(DEV), g_hidden).cpu()
     _report(f"text backward real dims {precision} dL/dx", gx, xr.grad)
-    tol = TOL if precision == "bf16x3" else 5e-2
-    assert rel_l2(gx, xr.grad) < tol
-    assert rel_max(gx[:, :16], xr.grad[:, :16]) < tol  # the context-token rows FullModel uses
+    if precision == "bf16x3":
+        assert rel_l2(gx, xr.grad) < TOL and rel_max(gx[:, :16], xr.grad[:, :16]) < TOL
+        return
+    # bf16: what the FORMAT costs a gradient is measured, not chosen -- torch autograd through the oracle with the operands
+    # rounded to bf16 at the kernels' rounding points (the casts pass gradients straight through) against the fp32 gradient;
+    # the HIP backward also rounds the gradient operands of its own GEMMs, so it is held to 2x that figure (VERDICT r03 item 8:
+    # the bound used to be a chosen 5e-2 against a measured 7e-3 .. 1.1e-2)
+    xe = x.clone().requires_grad_(True)
+    hidden_e, _, _ = clip_ref.text_transformer_raw(xe, sd, clip_ref.CONFIGS["ViT-B-16"], emulate="bf16")
+    feat_e = hidden_e[:, -1, :] @ sd["text_projection"]
+    feat_e = feat_e / feat_e.norm(dim=-1, keepdim=True)
+    (feat_e * gfeat).sum().backward()
+    floor_l2, floor_max = rel_l2(xe.grad, xr.grad), rel_max(xe.grad[:, :16], xr.grad[:, :16])
+    print(f"[parity] bf16 gradient floor (emulated forward, exact backward): rel_l2 {floor_l2:.3e} rel_max(ctx rows) {floor_max:.3e}; "
+          f"HIP: {rel_l2(gx, xr.grad):.3e} / {rel_max(gx[:, :16], xr.grad[:, :16]):.3e}")
+    assert rel_l2(gx, xr.grad) < 2 * floor_l2
+    assert rel_max(gx[:, :16], xr.grad[:, :16]) < 2 * floor_max  # the context-token rows FullModel uses
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
