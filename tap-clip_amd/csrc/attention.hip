@@ -92,8 +92,8 @@ __device__ __forceinline__ void store_o_mx8(const AttnArgs& a, const f32x4_t (&o
   if ((g & 1) == 0) a.out_q_scale[((size_t)head * a.out_m_pad + row) * 2 + (g >> 1)] = (uint8_t)byte;
 }
 
-template <int NKT, bool SPLIT>
-__global__ __launch_bounds__(512, (NKT % 2) ? 6 : 1) void attn_kernel(AttnArgs a) {
+template <int NKT, bool SPLIT, bool TIED = false>  // TIED: the last key counts exp(last_key_bias) times (tied.hip) -- its own
+__global__ __launch_bounds__(512, (NKT % 2) ? 6 : 1) void attn_kernel(AttnArgs a) {  // instantiation: the 80-VGPR build of the image tower must not carry it
   constexpr int KEYS = NKT * 16;
   constexpr int TILE = KEYS * 128;  // bytes of one [KEYS][64] bf16 image
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(512, (NKT % 2) ? 6 : 1) void attn_kernel(AttnArgs a
         }
       }
       // tied padding (tied.hip): the last key stands for m identical rows -- exp(s + ln m) = m exp(s)
-      if (a.last_key_bias != 0.f && kt == ((T - 1) >> 4)) {  // kernel-uniform
+      if (TIED && kt == ((T - 1) >> 4)) {  // kernel-uniform
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (4 * g + e == ((T - 1) & 15)) sc[kt][e] += a.last_key_bias;
@@ -575,18 +575,25 @@ hipError_t launch_flash(const AttnArgs& a, hipStream_t s) {
   return kb == 4 ? launch_flash_q<SPLIT, 2, 4>(a, s) : kb == 6 ? launch_flash_q<SPLIT, 2, 6>(a, s) : launch_flash_q<SPLIT, 2, 8>(a, s);
 }
 
-template <int NKT, bool SPLIT>
-hipError_t launch_t(const AttnArgs& a, hipStream_t s) {
+template <int NKT, bool SPLIT, bool TIED>
+hipError_t launch_tt(const AttnArgs& a, hipStream_t s) {
   static bool attr_set = false;
   const int smem_bytes = NKT * 16 * 128 * (SPLIT ? 4 : 2);
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<NKT, SPLIT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<NKT, SPLIT, TIED>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((attn_kernel<NKT, SPLIT>), dim3((unsigned)(a.n_seq * a.H)), dim3(512), smem_bytes, s, a);
+  hipLaunchKernelGGL((attn_kernel<NKT, SPLIT, TIED>), dim3((unsigned)(a.n_seq * a.H)), dim3(512), smem_bytes, s, a);
   return hipGetLastError();
+}
+template <int NKT, bool SPLIT>
+hipError_t launch_t(const AttnArgs& a, hipStream_t s) {
+  if constexpr (NKT % 2 == 0) {
+    if (a.last_key_bias != 0.f) return launch_tt<NKT, SPLIT, true>(a, s);
+  }
+  return launch_tt<NKT, SPLIT, false>(a, s);
 }
 
 template <bool SPLIT>
@@ -594,7 +601,7 @@ hipError_t dispatch(const AttnArgs& a, hipStream_t s) {
   // 197 tokens (ViT-B/16): 13 key tiles make the K and V images 2 x 26 KiB, so three workgroups fit a CU's LDS, and
   // that instantiation is compiled for 6 waves per SIMD (80 VGPRs)
   static const bool no13 = getenv("TAPCLIP_ATTN_NO13") != nullptr;
-  if (!SPLIT && !no13 && a.T > 192 && a.T <= 208) return launch_t<13, SPLIT>(a, s);
+  if (!SPLIT && !no13 && a.last_key_bias == 0.f && a.T > 192 && a.T <= 208) return launch_t<13, SPLIT>(a, s);
   const int nkt = ((a.T + 31) / 32) * 2;  // even number of 16-key tiles
   switch (nkt) {
     case 2: return launch_t<2, SPLIT>(a, s);
