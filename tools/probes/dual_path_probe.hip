@@ -8,6 +8,8 @@
 //   mode 0: all 32 pieces of a step by LDS-DMA                (what gemm256.hip does)
 //   mode 1: all 32 pieces by global_load_dwordx4 + ds_write_b128
 //   mode 2: A by LDS-DMA, W by global_load + ds_write         (16 + 16)
+// and, per mode, with every workgroup on its OWN A rows (half of the bytes come from beyond the XCD's L2, as in a GEMM whose A
+// tile is shared by few column tiles) or with only 12 distinct A tiles on the chip (everything an L2 hit after the first pass)
 // build: hipcc -O3 --offload-arch=gfx950 -o dual_path_probe dual_path_probe.hip ; run: ./dual_path_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -21,14 +23,14 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 constexpr int STAGE = 32 * 1024, NS = 4, KB = 768 * 2;  // bytes of a stage, ring depth, operand row bytes
 
 template <int MODE>
-__global__ __launch_bounds__(512) void probe(const uint8_t* A, const uint8_t* W, int steps, int ksteps, unsigned long long* cycles, uint32_t* sink) {
+__global__ __launch_bounds__(512) void probe(const uint8_t* A, const uint8_t* W, int steps, int ksteps, int a_tiles, unsigned long long* cycles, uint32_t* sink) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // piece j (16 rows x 64 B): wave w owns pieces w, w + 8 of A and of W; lane l -> row 16 j + (l >> 2), 16-B chunk l & 3
   uint32_t a_off[2], w_off[2];
   for (int i = 0; i < 2; ++i) {
     const int row = 16 * (wave + 8 * i) + (lane >> 2);
-    a_off[i] = (uint32_t)(((size_t)blockIdx.x * 256 + row) * KB + (lane & 3) * 16);
+    a_off[i] = (uint32_t)(((size_t)(blockIdx.x % a_tiles) * 256 + row) * KB + (lane & 3) * 16);  // a_tiles = grid: every workgroup its own A rows
     w_off[i] = (uint32_t)(((size_t)(blockIdx.x % 12) * 256 + row) * KB + (lane & 3) * 16);
   }
   u32x4_t ra[NS][2], rw[NS][2];
@@ -93,15 +95,16 @@ int main() {
   hipFuncSetAttribute((const void*)&probe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   hipFuncSetAttribute((const void*)&probe<2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   const char* names[3] = {"all LDS-DMA", "all global_load + ds_write", "A LDS-DMA, W global_load + ds_write"};
-  for (int wgs : {256, 128, 32}) {
+  for (int wgs : {256, 128, 32})
+   for (int a_tiles : {wgs, 12}) {
     for (int rep = 0; rep < 2; ++rep)
       for (int mode = 0; mode < 3; ++mode) {
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        if (mode == 0) hipLaunchKernelGGL(probe<0>, dim3(wgs), dim3(512), smem, 0, A, W, steps, ksteps, cyc, sink);
-        if (mode == 1) hipLaunchKernelGGL(probe<1>, dim3(wgs), dim3(512), smem, 0, A, W, steps, ksteps, cyc, sink);
-        if (mode == 2) hipLaunchKernelGGL(probe<2>, dim3(wgs), dim3(512), smem, 0, A, W, steps, ksteps, cyc, sink);
+        if (mode == 0) hipLaunchKernelGGL(probe<0>, dim3(wgs), dim3(512), smem, 0, A, W, steps, ksteps, a_tiles, cyc, sink);
+        if (mode == 1) hipLaunchKernelGGL(probe<1>, dim3(wgs), dim3(512), smem, 0, A, W, steps, ksteps, a_tiles, cyc, sink);
+        if (mode == 2) hipLaunchKernelGGL(probe<2>, dim3(wgs), dim3(512), smem, 0, A, W, steps, ksteps, a_tiles, cyc, sink);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms = 0;
@@ -112,7 +115,7 @@ int main() {
         for (auto v : h) avg += (double)v;
         avg /= wgs;
         if (rep == 1)
-          printf("%3d workgroups  %-38s  %7.1f us  %6.0f shader-clock ticks per 32-KiB step (s_memtime domain)  %5.1f GB/s per CU  %6.2f TB/s chip\n", wgs, names[mode],
+          printf("%3d workgroups  %3d A tiles  %-38s  %7.1f us  %6.0f shader-clock ticks per 32-KiB step (s_memtime domain)  %5.1f GB/s per CU  %6.2f TB/s chip\n", wgs, a_tiles, names[mode],
                  ms * 1e3, avg / steps, 32768.0 * steps / (ms * 1e-3) / 1e9, 32768.0 * steps * wgs / (ms * 1e-3) / 1e12);
       }
   }
