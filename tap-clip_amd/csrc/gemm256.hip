@@ -79,42 +79,6 @@ __device__ __forceinline__ void lds_read_b128_x1(uint32_t a0, u32x4_t& v0) {
 __device__ __forceinline__ void st16_policy(u32x4_t* p, const u32x4_t& v) { __builtin_nontemporal_store(v, p); }
 
 constexpr int BM = 256, BKS = 32;
-
-// tile id -> (row tile, column tile).  Two orders:
-//  * group_n == 0: groups of group_m row tiles x ALL column tiles, row tile fastest (rounds 1-3; group_m tuned per family).
-//  * group_n > 0 (round 4): the row tiles are cut into 8 SUPERBLOCKS -- XCD x owns a contiguous eighth of the ids, so a superblock
-//    is (nearly) one XCD's work -- and inside a superblock the ids run column-group by column-group (group_n column tiles), row
-//    tile by row tile, column tile fastest.  An XCD's 32 workgroups then cover 32 / group_n row tiles x group_n column tiles at a
-//    time, the W rows of a column group (group_n x 393 KB at K = 768) stay in the XCD's 4-MB L2 while ALL its row tiles stream past
-//    them, and an A row block is fetched from beyond the L2 once per column group instead of once per tile group.  What it is for:
-//    DESIGN.md section 4 "Round 4 (e)" -- the k-loop is bound by the L2s' delivery, and a quarter of c_fc's staged bytes were misses.
-__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int group_m, int group_n, int& tm, int& tn) {
-  if (group_n > 0) {
-    const int SB = (tiles_m + 7) >> 3;
-    const int per_sb = SB * tiles_n;
-    const int sb = id / per_sb;
-    const int first_m = sb * SB;
-    const int sbm = tiles_m - first_m < SB ? tiles_m - first_m : SB;
-    const int in_sb = id - sb * per_sb;
-    const int per_ng = sbm * group_n;
-    const int ng = in_sb / per_ng;
-    const int n_first = ng * group_n;
-    const int gn = tiles_n - n_first < group_n ? tiles_n - n_first : group_n;
-    const int in_ng = in_sb - ng * per_ng;
-    const int row = in_ng / gn;
-    tm = first_m + row;
-    tn = n_first + (in_ng - row * gn);
-    return;
-  }
-  const int per_group = group_m * tiles_n;
-  const int grp = id / per_group;
-  const int first_m = grp * group_m;
-  const int gsize = tiles_m - first_m < group_m ? tiles_m - first_m : group_m;
-  const int in_grp = id - grp * per_group;
-  const int col = in_grp / gsize;
-  tm = first_m + (in_grp - col * gsize);
-  tn = col;
-}
 constexpr int MAX_N_BIAS = 4096;  // bias vector kept in LDS
 
 template <int EPI, bool SPLIT, int BN, int NS>
@@ -195,12 +159,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
   const int KS = SPLIT ? 3 * KS1 : KS1;
   const int KSP = g.split_parts > 0 ? KS / g.split_parts : KS;  // K steps of a split part
 
-  // tile id -> (m0, n0): tile_coords above
+  // tile id -> (m0, n0): grouped ordering, group_m (8) m-tiles x all n-tiles per group, m fastest
+  // (gemm_bench: 6..12 are within 2 % of each other, 2 and 32 lose 5-10 %)
   auto tile_origin = [&](int id, int64_t& m0, int& n0) {
-    int tm, tn;
-    tile_coords(id, tiles_m, tiles_n, g.group_m, g.group_n, tm, tn);
-    m0 = (int64_t)tm * BM;
-    n0 = tn * BN;
+    const int GM = g.group_m;
+    const int per_group = GM * tiles_n;
+    const int grp = id / per_group;
+    const int first_m = grp * GM;
+    const int gsize = tiles_m - first_m < GM ? tiles_m - first_m : GM;
+    const int in_grp = id - grp * per_group;
+    m0 = (int64_t)(first_m + in_grp % gsize) * BM;
+    n0 = (in_grp / gsize) * BN;
   };
   // LDS-DMA source offsets (32-bit BYTE offsets: the launcher checks that A and W are < 4 GiB).
   // Piece j of a stage = rows 16j .. 16j+15; wave w issues pieces w, w + 8; lane l covers row
@@ -640,11 +609,14 @@ __global__ __launch_bounds__(256) void splitk_fixup_kernel(GemmArgs g, int n_til
   const int t = blockIdx.x / CHUNKS;                     // tail tile index
   const int e4 = (blockIdx.x % CHUNKS) * 256 + threadIdx.x;  // float4 index inside the tile
   const int rr = e4 / (BN / 4), c4 = e4 % (BN / 4);
-  // tile id -> origin (the GEMM kernel's own order)
-  int tm, tn;
-  tile_coords(g.split_from + t, tiles_m, tiles_n, g.group_m, g.group_n, tm, tn);
-  const int64_t m = (int64_t)tm * BM + rr;
-  const int n = tn * BN + c4 * 4;
+  // tile id -> origin (same grouped order as the GEMM kernel)
+  const int id = g.split_from + t;
+  const int GM = g.group_m;
+  const int per_group = GM * tiles_n, grp = id / per_group, first_m = grp * GM;
+  const int gsize = tiles_m - first_m < GM ? tiles_m - first_m : GM;
+  const int in_grp = id - grp * per_group;
+  const int64_t m = (int64_t)(first_m + in_grp % gsize) * BM + rr;
+  const int n = (in_grp / gsize) * BN + c4 * 4;
   if (t >= n_tiles || m >= g.M) return;
   f32x4_t v = g.bias ? *reinterpret_cast<const f32x4_t*>(g.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
   for (int p = 0; p < g.split_parts; ++p)

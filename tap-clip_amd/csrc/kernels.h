@@ -36,7 +36,6 @@ struct GemmArgs {
   const bf16_t* aux_hi = nullptr;  // EPI_GELU_BWD_BF16: upstream gradient dL/dh [M, N] (row stride ldo); may alias out
   const bf16_t* aux_lo = nullptr;
   int32_t group_m = 8;             // m-tiles per group of the grouped tile order (gemm256.hip)
-  int32_t group_n = 0;             // > 0: the superblock order of gemm256.hip (column tiles per column group)
   // gemm256.hip tail split: tiles >= split_from are each computed by split_parts workgroups over 1/split_parts
   // of K as raw fp32 partial tiles [256][BN] in split_ws; a fix-up kernel sums them and applies the epilogue
   float* split_ws = nullptr;       // caller-provided scratch, >= gemm256_split_ws_bytes()

@@ -316,26 +316,6 @@ int group_m_for(int slot) {
   }
 }
 
-// column tiles per column group of the superblock tile order (gemm256.hip tile_coords), per family; 0 = the grouped order above.
-// TAPCLIP_GN="q,o,f,p" (experiments / A-B).
-int group_n_for(int slot) {
-  static int gn[4] = {0, 0, 0, 0};
-  static const bool init = [] {
-    const char* e = getenv("TAPCLIP_GN");
-    if (e) sscanf(e, "%d,%d,%d,%d", &gn[0], &gn[1], &gn[2], &gn[3]);
-    for (int& v : gn) v = v < 0 ? 0 : v;
-    return true;
-  }();
-  (void)init;
-  switch (slot) {
-    case 2: return gn[0];
-    case 4: return gn[1];
-    case 5: return gn[2];
-    case 6: return gn[3];
-    default: return 0;
-  }
-}
-
 int group_m_mx8_for(int slot) {  // the same for the MXFP8 GEMM (TAPCLIP_GM8="q,o,f,p")
   static int gm[4] = {8, 8, 8, 8};
   static const bool init = [] {
@@ -392,7 +372,6 @@ int gemm(tapclip_tower* t, int slot, int epi, const bf16_t* a_hi, const bf16_t* 
   g.add_table = add_table; g.rows_per_group = rows_per_group;
   g.act = t->cfg.act;
   g.group_m = group_m_for(slot);
-  g.group_n = group_n_for(slot);
   ProfScope ps(t, slot, s);
   HIP_TRY(launch_gemm(g, epi, t->split, s));
   DBG_SYNC(2, s);
