@@ -497,6 +497,31 @@ def test_bench_spawns_its_ranks_at_the_configs3_shape(tmp_path):
             assert torch.equal(got[256 * rank: 256 * (rank + 1)], want), f"rows of rank {rank} differ from the single-process encode"
 
 
+def test_bench_checks_do_not_depend_on_the_number_of_steps(tmp_path):
+    """bench.py's precision table is evaluated at the SEEDED prompts (its prompt-tuning leg used to move
+    them first, with a step count that follows --steps, so `precisions.*.logits_*` -- and the arg-max agreement DESIGN.md once
+    quoted -- changed with the command line).  Two runs with different --steps: identical error fields in every precision, the
+    headline's own tolerance flag present, logits/s made of the full forward."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    lines = []
+    for steps in ("4", "24"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps, "--warmup", "1", "--no-input-side", "--no-configs4"],
+                           capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        lines.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
+    a, b = lines
+    assert set(a["precisions"]) == set(b["precisions"]) == {"bf16", "fp16", "bf16x3", "fp8"}
+    for p in a["precisions"]:
+        for k in ("logits_rel_max_vs_cpu_oracle", "logits_rel_l2_vs_cpu_oracle", "meets_1e-3", "logits_err_over_top2_margin", "embedding_rel_l2_vs_bf16x3"):
+            assert a["precisions"][p][k] == b["precisions"][p][k], (p, k, a["precisions"][p][k], b["precisions"][p][k])
+    assert a["headline_meets_tolerance"] is False and a["precisions"]["fp16"]["meets_1e-3"] and a["precisions"]["bf16x3"]["meets_1e-3"]
+    assert a["parity_mode"]["precision"] == "fp16" and a["parity_mode"]["roofline"]["frac"] > 0.2
+    ff = a["full_forward"]
+    assert ff["cls_only_last_block"] is False and abs(a["logits_per_sec"] - 256 * 65 / (ff["ms_per_forward"] * 1e-3)) < 1e-3 * a["logits_per_sec"]
+
+
 def test_vit_l14_336_batch_128_properties(eng):
     """BASELINE configs[4] at its per-GPU size: ViT-L/14@336, batch 128, fp8 image tower -- finite, unit norms, run-to-run
     bit-identical, and the two golden images inside the big batch equal their batch-2 rows (to the mode's round-off: the
