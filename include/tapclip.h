@@ -223,6 +223,17 @@ int tapclip_build_prompts(const float* ctx, const float* tok, const float* attri
                           int32_t attr_cols, int32_t n, int32_t P, int32_t L, int32_t D, float* out,
                           tapclip_stream_t stream);
 
+/* ---- `PromptAdjustor('gate' | 'residual')` (reference models/prompt_adjustor.py:13-25,38-44; no reference script selects them)
+ * fused with the same two concatenations: a = attribution[n, t]; h = relu(w1 a + b1) with w1, b1 [64] (nn.Linear(1, 64));
+ *   TAPCLIP_ADJUST_GATE:     out[n, t] = ctx[n, t] * sigmoid(w2 . h + b2)      w2 [64] (nn.Linear(64, 1).weight), b2 [1]
+ *   TAPCLIP_ADJUST_RESIDUAL: out[n, t] = ctx[n, t] + (W2 h + b2)               W2 [D, 64] (nn.Linear(64, D).weight), b2 [D]
+ * out[n, P:] = tok[n].  Forward only: a training step that optimises the adjustor's own weights keeps the torch modules. */
+#define TAPCLIP_ADJUST_GATE 1
+#define TAPCLIP_ADJUST_RESIDUAL 2
+int tapclip_build_prompts_mlp(int32_t method, const float* ctx, const float* tok, const float* attribution, int32_t attr_cols,
+                              const float* w1, const float* b1, const float* w2, const float* b2, int32_t n, int32_t P,
+                              int32_t L, int32_t D, float* out, tapclip_stream_t stream);
+
 /* ---- cosine logits (reference models/model_wrapper.py:79,83):
  * out[b,c] = scale * sum_e img[b,e] * txt[c,e]; img, txt already L2-normalised. */
 int tapclip_logits(const float* img, const float* txt, float scale, int32_t B, int32_t C, int32_t E,

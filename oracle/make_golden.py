@@ -72,6 +72,19 @@ def g_prompt_adjustor(ref):
     a = torch.softmax(torch.randn(3, 16), dim=-1)
     a1 = torch.ones(3, 1)
     _save("prompt_adjustor", prompt=p, attribution=a, out=pa(p, a), attribution_b1=a1, out_b1=pa(p, a1))
+    # the two methods no reference script selects (prompt_adjustor.py:13-25,38-44): their small MLPs as the reference's own
+    # module initialises and evaluates them -- parameters and outputs committed
+    extra = {}
+    for method, net in (("gate", "gate_net"), ("residual", "residual_net")):
+        torch.manual_seed(13)
+        m = ref["PromptAdjustor"](method)
+        with torch.no_grad():
+            extra[f"{method}_out"] = m(p, a)
+            extra[f"{method}_out_b1"] = m(p, a1.expand(3, 16).contiguous())
+        seq = getattr(m, net)
+        extra[f"{method}_w1"], extra[f"{method}_b1"] = seq[0].weight.detach(), seq[0].bias.detach()
+        extra[f"{method}_w2"], extra[f"{method}_b2"] = seq[2].weight.detach(), seq[2].bias.detach()
+    _save("prompt_adjustor_mlp", prompt=p, attribution=a, **extra)
 
 
 def _full_model_case(ref, cfg, sd, class_names, prompt_len, B, semantics, seed_img, with_grads=True):

@@ -48,6 +48,7 @@ SYMBOLS = [
     ("tapclip_embed_tokens", _i32, [_p, _p, _i32, _i32, _i32, _p, _p]),
     ("tapclip_attribution", _i32, [_p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     ("tapclip_build_prompts", _i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
+    ("tapclip_build_prompts_mlp", _i32, [_i32, _p, _p, _p, _i32, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
     ("tapclip_logits", _i32, [_p, _p, _f32, _i32, _i32, _i32, _p, _p]),
     ("tapclip_preprocess_u8", _i32, [_p, _p, _i32, _i32, _p, _p, _p, _p]),
     ("tapclip_layernorm_f32", _i32, [_p, _p, _p, _i64, _i32, _p, _p]),
@@ -72,6 +73,7 @@ ACT_GELU_ERF, ACT_QUICK_GELU = 0, 1
 PREC_BF16, PREC_BF16X3, PREC_FP8 = 0, 1, 2
 # "fp16" is the bf16 code path of the IEEE-half build of the library
 PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp8": PREC_FP8, "fp16": PREC_BF16}
+ADJUST_GATE, ADJUST_RESIDUAL = 1, 2
 FLAG_PRUNE_LAST_BLOCK = 1
 FLAG_KSPLIT = 2  # K-split of partial GEMM rounds over idle CUs: latency (1, default) against CU-time (0)
 PROFILE_SLOTS = ("patch_embed", "layernorm", "gemm_qkv", "attention", "gemm_out_proj", "gemm_fc_gelu",

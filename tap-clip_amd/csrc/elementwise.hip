@@ -435,10 +435,53 @@ hipError_t launch_attribution(const float* amap, int32_t n, int32_t T, int32_t T
   return hipGetLastError();
 }
 
+// PromptAdjustor 'gate' / 'residual' (reference models/prompt_adjustor.py:13-25,38-44) fused with the two concatenations, like
+// build_prompts_kernel for 'scale': per context token a = attribution[n, t] -> h = relu(w1 a + b1) (64 units) ->
+//   gate:     g = sigmoid(w2 . h + b2),       out = ctx * g            (w2 [1, 64])
+//   residual: delta = W2 h + b2,              out = ctx + delta        (W2 [D, 64], the reference hard-codes D = 512)
+// One thread per output element; the 64 hidden units are recomputed per thread (64 FMAs: cheaper than a round trip).
+constexpr int ADJ_HIDDEN = 64;
+template <int METHOD>  // 1 = gate, 2 = residual
+__global__ __launch_bounds__(256) void build_prompts_mlp_kernel(const float* __restrict__ ctx, const float* __restrict__ tok,
+                                                                const float* __restrict__ attr, int attr_cols,
+                                                                const float* __restrict__ w1, const float* __restrict__ b1,
+                                                                const float* __restrict__ w2, const float* __restrict__ b2, int P, int L,
+                                                                int D, int64_t total, float* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int T = P + L;
+  const int64_t n = i / ((int64_t)T * D);
+  const int64_t rem = i - n * T * D;
+  const int t = (int)(rem / D), c = (int)(rem - (int64_t)t * D);
+  if (t >= P) {
+    out[i] = tok[(n * L + (t - P)) * D + c];
+    return;
+  }
+  const float a = attr[n * attr_cols + (attr_cols == 1 ? 0 : t)];
+  float acc = METHOD == 1 ? b2[0] : b2[c];
+  const float* w2r = METHOD == 1 ? w2 : w2 + (int64_t)c * ADJ_HIDDEN;
+#pragma unroll 8
+  for (int j = 0; j < ADJ_HIDDEN; ++j) acc = fmaf(w2r[j], fmaxf(fmaf(w1[j], a, b1[j]), 0.f), acc);
+  const float x = ctx[(n * P + t) * D + c];
+  out[i] = METHOD == 1 ? x * (1.0f / (1.0f + expf(-acc))) : x + acc;
+}
+
 hipError_t launch_build_prompts(const float* ctx, const float* tok, const float* attr, int32_t attr_cols, int32_t n,
                                 int32_t P, int32_t L, int32_t D, float* out, hipStream_t s) {
   const int64_t total = (int64_t)n * (P + L) * D;
   hipLaunchKernelGGL(build_prompts_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, ctx, tok, attr, attr_cols, P, L, D, total, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_build_prompts_mlp(int method, const float* ctx, const float* tok, const float* attr, int32_t attr_cols, const float* w1,
+                                    const float* b1, const float* w2, const float* b2, int32_t n, int32_t P, int32_t L, int32_t D, float* out,
+                                    hipStream_t s) {
+  const int64_t total = (int64_t)n * (P + L) * D;
+  if (method == 1)
+    hipLaunchKernelGGL(build_prompts_mlp_kernel<1>, dim3(blocks_for(total, 256)), dim3(256), 0, s, ctx, tok, attr, attr_cols, w1, b1, w2, b2, P, L, D, total, out);
+  else if (method == 2)
+    hipLaunchKernelGGL(build_prompts_mlp_kernel<2>, dim3(blocks_for(total, 256)), dim3(256), 0, s, ctx, tok, attr, attr_cols, w1, b1, w2, b2, P, L, D, total, out);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 

@@ -1268,6 +1268,17 @@ int tapclip_build_prompts(const float* ctx, const float* tok, const float* attri
   return TAPCLIP_OK;
 }
 
+int tapclip_build_prompts_mlp(int32_t method, const float* ctx, const float* tok, const float* attribution, int32_t attr_cols,
+                              const float* w1, const float* b1, const float* w2, const float* b2, int32_t n, int32_t P, int32_t L, int32_t D,
+                              float* out, tapclip_stream_t stream) {
+  if (!ctx || !tok || !attribution || !w1 || !b1 || !w2 || !b2 || !out || n <= 0 || P <= 0 || L <= 0 || D <= 0)
+    return fail(TAPCLIP_EINVAL, "bad build_prompts_mlp arguments");
+  if (method != TAPCLIP_ADJUST_GATE && method != TAPCLIP_ADJUST_RESIDUAL) return fail(TAPCLIP_EINVAL, "unknown adjustor method %d", method);
+  if (attr_cols != P && attr_cols != 1) return fail(TAPCLIP_EINVAL, "attribution has %d columns, expected %d or 1", attr_cols, P);
+  HIP_TRY(launch_build_prompts_mlp(method, ctx, tok, attribution, attr_cols, w1, b1, w2, b2, n, P, L, D, out, static_cast<hipStream_t>(stream)));
+  return TAPCLIP_OK;
+}
+
 int tapclip_logits(const float* img, const float* txt, float scale, int32_t B, int32_t C, int32_t E, float* out,
                    tapclip_stream_t stream) {
   if (!img || !txt || !out || B <= 0 || C <= 0 || E <= 0) return fail(TAPCLIP_EINVAL, "bad logits arguments");

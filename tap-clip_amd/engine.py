@@ -333,6 +333,26 @@ def build_prompts(ctx: torch.Tensor, tok: torch.Tensor, attr: Optional[torch.Ten
     return out
 
 
+def build_prompts_mlp(ctx: torch.Tensor, tok: torch.Tensor, attr: torch.Tensor, adjustor) -> torch.Tensor:
+    """cat([PromptAdjustor('gate' | 'residual')(ctx, attr), tok], dim=1) in one kernel (reference
+    models/prompt_adjustor.py:38-44, models/model_wrapper.py:68-69); forward only, the adjustor's weights as they are."""
+    method = {"gate": _lib.ADJUST_GATE, "residual": _lib.ADJUST_RESIDUAL}[adjustor.method]
+    net = adjustor.gate_net if adjustor.method == "gate" else adjustor.residual_net
+    c = ctx.detach().to(torch.float32).contiguous()
+    dev = c.device
+    f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+    t, a = f(tok), f(attr)
+    w1, b1, w2, b2 = f(net[0].weight).view(-1), f(net[0].bias), f(net[2].weight), f(net[2].bias)
+    n, P, D = c.shape
+    if adjustor.method == "residual" and w2.shape[0] != D:
+        raise ValueError(f"PromptAdjustor('residual') produces {w2.shape[0]} columns, the context tokens have {D}")  # (torch would fail to broadcast)
+    out = torch.empty(n, P + t.shape[1], D, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().tapclip_build_prompts_mlp(method, _ptr(c), _ptr(t), _ptr(a), a.shape[1], _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2),
+                                                         n, P, t.shape[1], D, _ptr(out), _stream_ptr(dev)))
+    return out
+
+
 def logits(img: torch.Tensor, txt: torch.Tensor, scale: float) -> torch.Tensor:
     """scale * img @ txt.T (reference models/model_wrapper.py:79,83)."""
     i = img.detach().to(torch.float32).contiguous()

@@ -240,6 +240,8 @@ class FullModel(nn.Module):
         # pass 2: adjusted prompt -> last token -> projection -> norm (model_wrapper.py:68-75)
         if fused:
             adjusted = engine.build_prompts(ctx, tok, attribution)
+        elif not torch.is_grad_enabled() and ctx.is_cuda:
+            adjusted = engine.build_prompts_mlp(ctx, tok, attribution, self.prompt_adjustor)   # 'gate' / 'residual', one kernel
         else:
             adjusted = torch.cat([self.prompt_adjustor(ctx, attribution), tok], dim=1)
         hidden = clip.model.transformer(adjusted, _tail_run=run)

@@ -4,8 +4,9 @@ Drop-in for reference models/prompt_adjustor.py:6-47.  'scale' (the only method 
 script selects: train.py:61, test_cross_domain.py:40, test_cross_domain2.py:78) multiplies every
 context token by its attribution score; in `FullModel` it is fused with the prompt concatenation
 into one HIP kernel (`tapclip_build_prompts`).  'gate' and 'residual' keep the reference's small
-MLPs (1->64->1 sigmoid gate; 1->64->512 residual) and run as ordinary torch modules: they are
-host-side extras off the accelerated path."""
+MLPs (1->64->1 sigmoid gate; 1->64->512 residual) as torch modules -- they hold trainable weights -- and
+`FullModel`'s no-grad forward evaluates them in one HIP kernel too (`tapclip_build_prompts_mlp`); a pass
+that differentiates goes through the modules."""
 import torch
 import torch.nn as nn
 

@@ -379,6 +379,35 @@ def test_small_ops_vs_reference_goldens(eng):
     assert rel_max(lg, 14.2857 * img @ txt.t()) < 1e-5
 
 
+@pytest.mark.parametrize("method", ["gate", "residual"])
+def test_prompt_adjustor_mlp_kernel_vs_reference(eng, method):
+    """`tapclip_build_prompts_mlp` against the outputs of the reference's own PromptAdjustor('gate' | 'residual') (goldens carry
+    the parameters its module drew): adjusted context rows, token rows copied behind them, a broadcast [n, 1] attribution too;
+    and FullModel's no-grad forward takes the kernel while its training forward keeps the differentiable modules -- same logits."""
+    from tap_clip_amd.models.prompt_adjustor import PromptAdjustor
+
+    g = golden("prompt_adjustor_mlp")
+    m = PromptAdjustor(method).to(DEV)
+    net = m.gate_net if method == "gate" else m.residual_net
+    with torch.no_grad():
+        net[0].weight.copy_(torch.from_numpy(g[f"{method}_w1"])); net[0].bias.copy_(torch.from_numpy(g[f"{method}_b1"]))
+        net[2].weight.copy_(torch.from_numpy(g[f"{method}_w2"])); net[2].bias.copy_(torch.from_numpy(g[f"{method}_b2"]))
+    p, at = torch.from_numpy(g["prompt"]).to(DEV), torch.from_numpy(g["attribution"]).to(DEV)
+    tok = synth.normal([3, 7, 512], 3, "adj.tok").to(DEV)
+    out = eng.build_prompts_mlp(p, tok, at, m).cpu()
+    assert rel_max(out[:, :16], torch.from_numpy(g[f"{method}_out"])) < 2e-6 and torch.equal(out[:, 16:], tok.cpu())
+    out1 = eng.build_prompts_mlp(p, tok, torch.ones(3, 1, device=DEV), m).cpu()
+    assert rel_max(out1[:, :16], torch.from_numpy(g[f"{method}_out_b1"])) < 2e-6
+    if method == "gate":  # (the reference hard-codes 512 output columns for 'residual': only D = 512 models can run it; tiny has 128)
+        gt = golden("fullmodel_intended_tiny")
+        model, images = _build_full("tiny", gt, "intended", "bf16x3")
+        model.prompt_adjustor = PromptAdjustor("gate").to(DEV)
+        with torch.no_grad():
+            a = model(images)["logits"]                       # kernel path
+        b = model.train()(images)["logits"].detach()           # torch modules (autograd path)
+        assert rel_max(a.cpu(), b.cpu()) < 1e-4
+
+
 # ---- FullModel vs the reference's own FullModel (goldens) ----------------------------------------
 def _build_full(cfg_name, g, semantics, precision, collapse=True):
     from tap_clip_amd.models import CLIPWrapper, FullModel

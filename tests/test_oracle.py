@@ -38,6 +38,22 @@ def test_adjust_matches_reference():
     assert torch.equal(p * torch.from_numpy(g["attribution_b1"]).unsqueeze(-1), torch.from_numpy(g["out_b1"]))
 
 
+@pytest.mark.parametrize("method", ["gate", "residual"])
+def test_prompt_adjustor_mlp_methods_match_reference(method):
+    """`PromptAdjustor('gate' | 'residual')` (reference models/prompt_adjustor.py:13-25,38-44): the mirror class carrying the
+    weights the reference's own module drew reproduces its outputs (goldens: parameters + outputs of the reference class)."""
+    from tap_clip_amd.models.prompt_adjustor import PromptAdjustor
+
+    g = golden("prompt_adjustor_mlp")
+    m = PromptAdjustor(method)
+    net = m.gate_net if method == "gate" else m.residual_net
+    with torch.no_grad():
+        net[0].weight.copy_(torch.from_numpy(g[f"{method}_w1"])); net[0].bias.copy_(torch.from_numpy(g[f"{method}_b1"]))
+        net[2].weight.copy_(torch.from_numpy(g[f"{method}_w2"])); net[2].bias.copy_(torch.from_numpy(g[f"{method}_b2"]))
+        out = m(torch.from_numpy(g["prompt"]), torch.from_numpy(g["attribution"]))
+    assert rel_max(out, torch.from_numpy(g[f"{method}_out"])) < 1e-6
+
+
 @pytest.mark.parametrize("semantics", ["literal", "intended"])
 def test_fullmodel_tiny_matches_reference(semantics):
     """logits / loss / attention capture of the reference FullModel (tiny towers, B=4, 3 classes)."""
