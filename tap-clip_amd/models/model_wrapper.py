@@ -183,7 +183,9 @@ class FullModel(nn.Module):
             return feat, labels, None
         dev = images.device
         if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=dev)
+            # (TAPCLIP_IMAGE_STREAM_PRIORITY: experiments -- -1 asks for a high-priority stream; measured twice, rounds 3 and 4: no effect)
+            prio = int(os.environ.get("TAPCLIP_IMAGE_STREAM_PRIORITY", "0"))
+            self._side_stream = torch.cuda.Stream(device=dev, priority=prio)
         side = self._side_stream
         side.wait_stream(torch.cuda.current_stream(dev))  # the images (and labels) were produced on the caller's stream
         with torch.cuda.stream(side):
