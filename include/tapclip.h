@@ -314,15 +314,6 @@ void tapclip_comm_destroy(tapclip_comm_t* comm);
  * the Python FullModel switches it off for its forward and back on for the backward.  Results differ between the two
  * settings by fp32 summation order only (the rounding-level dependence documented for the tail split). */
 #define TAPCLIP_FLAG_KSPLIT 2
-/* TAPCLIP_FLAG_PACE (text towers, default 0 = off; value = kernels per window, 1..64): the text tower's kernels are let go in groups
- * of `value` per WINDOW of the image tower set by tapclip_tower_set_pacer -- the memory-bound stretch (attention, LayerNorm) behind each
- * of its QKV / out_proj / c_proj GEMMs, marked by a HIP event -- so that, with both towers of FullModel.forward in flight on two
- * streams (reference models/model_wrapper.py:40-75), the text tower's small grids run beside the image tower's LayerNorm / attention
- * kernels instead of in front of its persistent GEMMs' statically dealt tiles.  Ordering only: results are unchanged.  With no image
- * tower in flight the events are already complete and the waits cost nothing.  The pacer must outlive the paced tower or be unset
- * (tapclip_tower_set_pacer(text, NULL)). */
-#define TAPCLIP_FLAG_PACE 3
-int tapclip_tower_set_pacer(tapclip_tower_t* text, tapclip_tower_t* vision);
 int tapclip_tower_set_flag(tapclip_tower_t* tower, int32_t flag, int32_t value);
 /* the current value of a flag (a caller that changes one for a while restores what it found, not the default) */
 int tapclip_tower_get_flag(const tapclip_tower_t* tower, int32_t flag, int32_t* value);

@@ -60,7 +60,6 @@ SYMBOLS = [
     ("tapclip_comm_create", _i32, [_p, _i32, _i32, C.POINTER(_p)]),
     ("tapclip_allgather", _i32, [_p, _p, _p, _sz, _p]),
     ("tapclip_comm_destroy", None, [_p]),
-    ("tapclip_tower_set_pacer", _i32, [_p, _p]),
     ("tapclip_tower_set_flag", _i32, [_p, _i32, _i32]),
     ("tapclip_tower_get_flag", _i32, [_p, _i32, C.POINTER(_i32)]),
     ("tapclip_profile_enable", _i32, [_p, _i32]),
@@ -76,7 +75,6 @@ PREC_BF16, PREC_BF16X3, PREC_FP8 = 0, 1, 2
 PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp8": PREC_FP8, "fp16": PREC_BF16}
 ADJUST_GATE, ADJUST_RESIDUAL = 1, 2
 FLAG_PRUNE_LAST_BLOCK = 1
-FLAG_PACE = 3    # text tower: kernels per window of the pacing image tower (0 = off)
 FLAG_KSPLIT = 2  # K-split of partial GEMM rounds over idle CUs: latency (1, default) against CU-time (0)
 PROFILE_SLOTS = ("patch_embed", "layernorm", "gemm_qkv", "attention", "gemm_out_proj", "gemm_fc_gelu",
                  "gemm_proj", "pool_proj", "pooled_tail")

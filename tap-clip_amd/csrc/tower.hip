@@ -97,18 +97,6 @@ struct tapclip_tower {
   int* bad_token = nullptr;   // device flag of tapclip_embed_tokens: set when a token id is outside the table
   int* tied_flag = nullptr;   // device flag of the tied-padding entry points (tied.hip): raised when the claimed run of identical rows is not one
   float* split_ws = nullptr;  // scratch for the K-split tail tiles of gemm256.hip (64 MiB, handle-owned)
-  // pacing (TAPCLIP_FLAG_PACE): an image tower records an event behind each of its QKV / out_proj / c_proj GEMMs -- the start of
-  // the memory-bound window (attention, LayerNorm) that follows -- and a text tower paced by it lets `pace_k` of its kernels go
-  // per window, so that its small grids run beside the image tower's LayerNorm / attention kernels and not in front of the
-  // persistent GEMMs' statically dealt tiles
-  std::vector<hipEvent_t> pace_events;  // image tower
-  int pace_n = 0;                       //   events recorded by the current encode_image
-  uint64_t pace_gen = 0;                //   bumped by every encode_image
-  bool pace_record = false;             //   some text tower is paced by this one
-  tapclip_tower* pacer = nullptr;       // text tower: the image tower whose windows gate it
-  int pace_k = 0;                       //   kernels per window (0 = not paced)
-  uint64_t pace_seen_gen = 0;
-  int pace_w = 0, pace_count = 0;
   // profiling
   bool prof_on = false;
   std::vector<ProfRec> prof;
@@ -365,30 +353,6 @@ constexpr int dbg_stop_at() { return 0; }
 #define DBG_SYNC(bit, s) do { } while (0)
 #endif
 
-// image tower: the window that opens behind the GEMM of `slot` (2 QKV -> attention, 4 out_proj -> LN2, 6 c_proj -> next LN1)
-int pace_mark(tapclip_tower* t, int slot, hipStream_t s) {
-  if (!t->pace_record || t->cfg.kind != TAPCLIP_TOWER_VISION || (slot != 2 && slot != 4 && slot != 6)) return TAPCLIP_OK;
-  if (t->pace_n == (int)t->pace_events.size()) {
-    hipEvent_t e;
-    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    t->pace_events.push_back(e);
-  }
-  HIP_TRY(hipEventRecord(t->pace_events[t->pace_n++], s));
-  return TAPCLIP_OK;
-}
-// text tower: before each of its kernels; every pace_k-th one waits for the image tower's next window
-int pace_tick(tapclip_tower* t, hipStream_t s) {
-  tapclip_tower* v = t->pacer;
-  if (v == nullptr || t->pace_k <= 0) return TAPCLIP_OK;
-  if (t->pace_seen_gen != v->pace_gen) {
-    t->pace_seen_gen = v->pace_gen;
-    t->pace_w = 0;
-    t->pace_count = 0;
-  }
-  if (t->pace_count++ % t->pace_k == 0 && t->pace_w < v->pace_n) HIP_TRY(hipStreamWaitEvent(s, v->pace_events[t->pace_w++], 0));
-  return TAPCLIP_OK;
-}
-
 int gemm(tapclip_tower* t, int slot, int epi, const bf16_t* a_hi, const bf16_t* a_lo, int64_t lda, const Packed& w,
          const float* bias, int64_t M, int N, int K, bf16_t* o_hi, bf16_t* o_lo, float* o_f32, int64_t ldo,
          hipStream_t s, const float* add_table = nullptr, int rows_per_group = 0, const bf16_t* aux_hi = nullptr,
@@ -408,12 +372,10 @@ int gemm(tapclip_tower* t, int slot, int epi, const bf16_t* a_hi, const bf16_t* 
   g.add_table = add_table; g.rows_per_group = rows_per_group;
   g.act = t->cfg.act;
   g.group_m = group_m_for(slot);
-  int rc = pace_tick(t, s);
-  if (rc) return rc;
   ProfScope ps(t, slot, s);
   HIP_TRY(launch_gemm(g, epi, t->split, s));
   DBG_SYNC(2, s);
-  return pace_mark(t, slot, s);
+  return TAPCLIP_OK;
 }
 
 int gemm_mx8(tapclip_tower* t, int slot, int epi, const uint8_t* a_q, const uint8_t* a_s, int64_t m_pad, const PackedMx8& w,
@@ -428,7 +390,7 @@ int gemm_mx8(tapclip_tower* t, int slot, int epi, const uint8_t* a_q, const uint
   g.group_m = group_m_mx8_for(slot);
   ProfScope ps(t, slot, s);
   HIP_TRY(launch_gemm_mx8(g, epi, s));
-  return pace_mark(t, slot, s);
+  return TAPCLIP_OK;
 }
 
 // The fp8 precision of the image tower (BASELINE.json configs[4]): the same block, with the four GEMMs on the
@@ -503,8 +465,6 @@ int run_blocks(tapclip_tower* t, float* x, int64_t n_seq, int tokens, int causal
     const LayerW& L = t->layers[li];
     const bool last = li == t->cfg.layers - 1;
     {
-      int prc = pace_tick(t, s);
-      if (prc) return prc;
       ProfScope ps(t, 1, s);
       // block l > 0: x still lacks BOTH branches of block l - 1 (its LN2 did not write x back)
       if (x24) {
@@ -530,7 +490,6 @@ int run_blocks(tapclip_tower* t, float* x, int64_t n_seq, int tokens, int causal
       a.probs = last ? probs_last : nullptr;
       a.n_seq = (int)n_seq; a.T = tokens; a.H = H; a.D = D; a.causal = causal;
       a.last_key_bias = last_key_bias;
-      if ((rc = pace_tick(t, s))) return rc;
       ProfScope ps(t, 3, s);
       HIP_TRY(launch_attention(a, t->split, s));
       DBG_SYNC(4, s);
@@ -544,7 +503,6 @@ int run_blocks(tapclip_tower* t, float* x, int64_t n_seq, int tokens, int causal
     rc = gemm(t, 4, EPI_BIAS_BF16, w.ao_hi, w.ao_lo, D, L.wo, L.bo, M, D, D, w.a_hi, w.a_lo, nullptr, D, s);
     if (rc) return rc;
     {
-      if ((rc = pace_tick(t, s))) return rc;
       ProfScope ps(t, 1, s);
       // LN2 normalises x + branch without writing x back (8 instead of 12 B/element); the last block does write,
       // so that only c_proj's branch is pending on return
@@ -687,7 +645,6 @@ int run_forward_saving(tapclip_tower* t, const float* x_in, int64_t n_seq, int t
   int rc;
   for (int li = 0; li < L; ++li) {
     const LayerW& Lw = t->layers[li];
-    if ((rc = pace_tick(t, s))) return rc;
     if (li == 0) HIP_TRY(launch_layernorm(sv.x0[0], D, Lw.ln1_g, Lw.ln1_b, M, D, w.xn_hi, w.xn_lo, nullptr, s));
     else HIP_TRY(launch_add_layernorm(sv.x1[li - 1], w.d_hi, w.d_lo, Lw.ln1_g, Lw.ln1_b, M, D, w.xn_hi, w.xn_lo, s, sv.x0[li]));
     if ((rc = gemm(t, 2, EPI_BIAS_BF16, w.xn_hi, w.xn_lo, D, Lw.wqkv, Lw.bqkv, M, 3 * D, D, sv.qkv_hi[li], sv.qkv_lo[li], nullptr, 3 * D, s))) return rc;
@@ -697,10 +654,8 @@ int run_forward_saving(tapclip_tower* t, const float* x_in, int64_t n_seq, int t
     a.probs = nullptr;
     a.n_seq = (int)n_seq; a.T = tokens; a.H = H; a.D = D; a.causal = causal;
     a.last_key_bias = last_key_bias;
-    if ((rc = pace_tick(t, s))) return rc;
     HIP_TRY(launch_attention(a, t->split, s));
     if ((rc = gemm(t, 4, EPI_BIAS_BF16, sv.ao_hi[li], sv.ao_lo[li], D, Lw.wo, Lw.bo, M, D, D, w.d_hi, w.d_lo, nullptr, D, s))) return rc;
-    if ((rc = pace_tick(t, s))) return rc;
     HIP_TRY(launch_add_layernorm(sv.x0[li], w.d_hi, w.d_lo, Lw.ln2_g, Lw.ln2_b, M, D, w.xn_hi, w.xn_lo, s, sv.x1[li]));
     if ((rc = gemm(t, 5, EPI_BIAS_GELU_BF16, w.xn_hi, w.xn_lo, D, Lw.wfc, Lw.bfc, M, F, D, w.h_hi, w.h_lo, nullptr, F, s))) return rc;
     if ((rc = gemm(t, 6, EPI_BIAS_BF16, w.h_hi, w.h_lo, F, Lw.wpr, Lw.bpr, M, D, F, w.d_hi, w.d_lo, nullptr, D, s))) return rc;
@@ -833,7 +788,6 @@ void tapclip_tower_destroy(tapclip_tower_t* t) {
     (void)hipEventDestroy(r.start);
     (void)hipEventDestroy(r.stop);
   }
-  for (hipEvent_t e : t->pace_events) (void)hipEventDestroy(e);
   delete t;
 }
 
@@ -957,8 +911,6 @@ int tapclip_encode_image(tapclip_tower_t* t, const float* images, int32_t B, flo
   const int N = t->tokens_vision, D = t->cfg.width, G2 = N - 1;
   const Workspace w = carve(t, B, N, workspace);
   if (w.bytes > workspace_bytes) return fail(TAPCLIP_EWORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, w.bytes);
-  t->pace_n = 0;  // (pacing: the windows of THIS call; a text tower paced by this one starts over when it sees the new generation)
-  ++t->pace_gen;
   {
     ProfScope ps(t, 0, s);
     // patch gather into the (not yet live) MLP-hidden buffer, then conv1-as-GEMM with the
@@ -1522,24 +1474,8 @@ int tapclip_tower_set_flag(tapclip_tower_t* t, int32_t flag, int32_t value) {
       t->prune_last = value != 0;
       return TAPCLIP_OK;
     case TAPCLIP_FLAG_KSPLIT: t->ksplit = value != 0; return TAPCLIP_OK;
-    case TAPCLIP_FLAG_PACE:
-      if (value < 0 || value > 64) return fail(TAPCLIP_EINVAL, "TAPCLIP_FLAG_PACE takes 0 (off) .. 64 kernels per window, got %d", value);
-      if (value > 0 && t->pacer == nullptr) return fail(TAPCLIP_ESTATE, "TAPCLIP_FLAG_PACE needs a pacer: tapclip_tower_set_pacer first");
-      t->pace_k = value;
-      return TAPCLIP_OK;
     default: return fail(TAPCLIP_EINVAL, "unknown tower flag %d", flag);
   }
-}
-
-int tapclip_tower_set_pacer(tapclip_tower_t* text, tapclip_tower_t* vision) {
-  if (!text) return fail(TAPCLIP_EINVAL, "null tower");
-  if (text->cfg.kind != TAPCLIP_TOWER_TEXT) return fail(TAPCLIP_EINVAL, "set_pacer: the paced tower must be a text tower");
-  if (vision && vision->cfg.kind != TAPCLIP_TOWER_VISION) return fail(TAPCLIP_EINVAL, "set_pacer: the pacer must be an image tower");
-  text->pacer = vision;
-  text->pace_seen_gen = 0;
-  if (vision) vision->pace_record = true;
-  else text->pace_k = 0;
-  return TAPCLIP_OK;
 }
 
 int tapclip_tower_get_flag(const tapclip_tower_t* t, int32_t flag, int32_t* value) {
@@ -1547,7 +1483,6 @@ int tapclip_tower_get_flag(const tapclip_tower_t* t, int32_t flag, int32_t* valu
   switch (flag) {
     case TAPCLIP_FLAG_PRUNE_LAST_BLOCK: *value = t->prune_last ? 1 : 0; return TAPCLIP_OK;
     case TAPCLIP_FLAG_KSPLIT: *value = t->ksplit ? 1 : 0; return TAPCLIP_OK;
-    case TAPCLIP_FLAG_PACE: *value = t->pace_k; return TAPCLIP_OK;
     default: return fail(TAPCLIP_EINVAL, "unknown tower flag %d", flag);
   }
 }

@@ -57,15 +57,6 @@ class _Tower:
         a tower that has the GPU to itself; off: fewest CU-seconds -- a tower that shares it with another stream)."""
         self._check(self.lib.tapclip_tower_set_flag(self.handle, _lib.FLAG_KSPLIT, int(bool(on))))
 
-    def set_pacer(self, vision: Optional["VisionTower"]) -> None:
-        """Text towers: the image tower whose memory-bound windows gate this tower's kernels while `set_pace(k > 0)` is on
-        (include/tapclip.h TAPCLIP_FLAG_PACE)."""
-        self._check(self.lib.tapclip_tower_set_pacer(self.handle, None if vision is None else vision.handle))
-        self._pacer = vision  # (keeps the image tower alive as long as this tower points at it)
-
-    def set_pace(self, kernels_per_window: int) -> None:
-        self._check(self.lib.tapclip_tower_set_flag(self.handle, _lib.FLAG_PACE, int(kernels_per_window)))
-
     def get_ksplit(self) -> bool:
         v = C.c_int32(0)
         self._check(self.lib.tapclip_tower_get_flag(self.handle, _lib.FLAG_KSPLIT, C.byref(v)))

@@ -220,7 +220,6 @@ class CLIPWrapper(nn.Module):
         # the HIP towers (weights packed to bf16 hi/lo inside the handles); strict=True semantics
         self._vision = engine.VisionTower(self.cfg, state_dict, dev, precision)
         self._text = engine.TextTower(self.cfg, state_dict, dev, precision)
-        self._pair_towers()
 
         # a later load_state_dict (reference test_cross_domain.py:61 loads `clip.model.*` back with
         # strict=False) must also reach the packed copies inside the HIP handles
@@ -278,18 +277,7 @@ class CLIPWrapper(nn.Module):
             dev = torch.device(module.device)
             module._vision = engine.VisionTower(module.cfg, sd, dev, module.precision)
             module._text = engine.TextTower(module.cfg, sd, dev, module.precision)
-            module._pair_towers()
             module.weights_version += 1
-
-    def _pair_towers(self) -> None:
-        """The text tower may be paced by this wrapper's image tower (FullModel switches the pacing on for its overlapped
-        forward passes only: include/tapclip.h TAPCLIP_FLAG_PACE).  In the fp16 mode the two handles belong to two builds of
-        the SAME sources (libtapclip_fp16.so / libtapclip.so: the macro that differs touches device code only), so the text
-        tower's library reads the image tower's window events through an identical host-side layout; the ABI versions are
-        compared to keep it that way."""
-        self._text_paced = self._vision.lib.tapclip_abi_version() == self._text.lib.tapclip_abi_version()
-        if self._text_paced:
-            self._text.set_pacer(self._vision)
 
     # ---- reference surface -----------------------------------------------------------------
     def reset(self) -> None:

@@ -158,9 +158,6 @@ class FullModel(nn.Module):
                         t.set_ksplit(v)
                     raise
                 clip._forward_gemms_saved = list(zip(towers, before))
-                pace = int(os.environ.get("TAPCLIP_PACE_K", "0"))  # (kernels of the text tower per window of the image tower; 0 = off)
-                if pace > 0 and getattr(clip, "_text_paced", False):
-                    clip._text.set_pace(pace)
             clip._forward_gemms_depth = getattr(clip, "_forward_gemms_depth", 0) + 1
 
         def __exit__(self, *exc):
@@ -171,8 +168,6 @@ class FullModel(nn.Module):
                 for (old, v), t in zip(clip._forward_gemms_saved, live):
                     t.set_ksplit(v)
                 clip._forward_gemms_saved = []
-                if getattr(clip, "_text_paced", False):
-                    clip._text.set_pace(0)
             return False
 
     # ---- image side ----------------------------------------------------------------------------
