@@ -528,6 +528,12 @@ def main():
         dt_full = timed_all_ranks(fwd, n_it)
         vision.set_prune_last_block(True)
         dt = timed_all_ranks(fwd, n_it)
+        # for the record: the same forward with EVERY row of every prompt through the text tower (the repeated padding rows not
+        # merged) -- same logits, the figure round 3 reported
+        tied_before = model.tie_padding
+        model.tie_padding = False
+        dt_untied = timed_all_ranks(fwd, max(3, n_it // 3))
+        model.tie_padding = tied_before
         is_cfg2 = (args.model, args.batch, args.classes, args.prompt_len) == ("ViT-B-16", 256, 65, 16)
         result["logits_per_sec"] = round(gb * args.classes / dt_full, 1)
         result["full_forward"] = {
@@ -538,7 +544,8 @@ def main():
             "images_per_sec": round(gb / dt_full, 1), "cls_only_last_block": False,
             "text_rows_per_sequence": {"input": args.prompt_len + cfg.ctx, "computed": args.prompt_len + cfg.ctx - model._tail_run() + 1,
                                        "why": "the padding rows of a prompt are one embedding row repeated and the reference adds no position / mask "
-                                              "(models/model_wrapper.py:58,72): the text tower runs on the distinct rows (include/tapclip.h, tied padding rows)"},
+                                              "(models/model_wrapper.py:58,72): the text tower runs on the distinct rows (include/tapclip.h, tied padding rows)",
+                                       "ms_per_forward_every_row": round(1e3 * dt_untied, 3)},
             "default_path": {"ms_per_forward": round(1e3 * dt, 3), "logits_per_sec": round(gb * args.classes / dt, 1),
                              "images_per_sec": round(gb / dt, 1), "cls_only_last_block": True}}
         # prompt-tuning step (reference train.py:99-105): forward + loss + backward to context_bank + AdamW, library defaults

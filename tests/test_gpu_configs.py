@@ -474,6 +474,7 @@ def test_bench_spawns_its_ranks_at_the_configs3_shape(tmp_path):
     assert "4 ranks" in ff["workload"] and ff["cls_only_last_block"] is False and ff["default_path"]["cls_only_last_block"] is True
     assert abs(res["logits_per_sec"] - 1024 * 65 / (ff["ms_per_forward"] * 1e-3)) < 1e-3 * res["logits_per_sec"]
     assert ff["text_rows_per_sequence"] == {**ff["text_rows_per_sequence"], "input": 93, "computed": 24}
+    assert ff["text_rows_per_sequence"]["ms_per_forward_every_row"] > 0
     assert res["train_step"]["ms_per_step"] > ff["default_path"]["ms_per_forward"]
     got = torch.from_numpy(np.load(out))
     assert got.shape == (1024, 65) and bool(torch.isfinite(got).all())
