@@ -86,6 +86,24 @@ def test_tied_forward_equals_untied(precision, name, n, P, runs):
     assert rel_l2(part["hidden"].cpu(), full["hidden"].cpu()) < tol
 
 
+@pytest.mark.parametrize("run", [13, 12])
+def test_tied_forward_at_the_degenerate_ends(run):
+    """A sequence that is ONE row repeated (tail_run = T: a single distinct row, its own key counted T times) and one with a
+    single other row in front: the merged tower still equals the untied one."""
+    tower, cfg = _text_tower("tiny", "bf16x3")
+    D, T = cfg.text.width, 13
+    x = synth.normal([3, 1, D], 9, "tied.one").expand(3, T, D).clone()
+    if run == 12:
+        x[:, 0] = synth.normal([3, D], 9, "tied.first")
+    x = x.to(DEV)
+    assert tower.tail_run(x) == run
+    full = tower.forward(x, want_mean=True, want_heads=True)
+    tied = tower.forward(x, want_mean=True, want_heads=True, tail_run=run)
+    for k in ("hidden", "attn_mean", "attn_heads"):
+        assert rel_max(tied[k].cpu(), full[k].cpu()) < 1e-4, k
+    assert not tower.tied_violations()
+
+
 def test_false_claim_poisons_the_outputs_until_acknowledged():
     tower, cfg = _text_tower("tiny", "bf16x3")
     x = _prompts(3, 5, cfg.ctx, cfg.text.width, [10]).to(DEV)
