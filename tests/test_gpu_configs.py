@@ -593,14 +593,15 @@ def test_ksplit_flag_changes_summation_order_only_and_fullmodel_restores_it(eng)
     assert torch.equal(on, tower.encode_image(images, normalize=True))
 
 
-@pytest.mark.parametrize("name,batch", [("ViT-B-16", 64), ("ViT-B-32", 8), ("ViT-L-14-336", 3), ("tiny", 1100)])
+@pytest.mark.parametrize("name,batch", [("ViT-B-16", 64), ("ViT-B-32", 8), ("ViT-B-32-quickgelu", 8), ("ViT-L-14-336", 3), ("tiny", 1100)])
 def test_pruned_last_block_equals_the_full_computation(eng, name, batch):
     """The library default computes the image tower's LAST block for the CLS rows only (K and V for every token; Q, the
     attention core, out_proj, LN2, the MLP for the pooled row: include/tapclip.h TAPCLIP_FLAG_PRUNE_LAST_BLOCK) -- the rows
     the reference's pooling throws away (models/clip_wrapper.py:46-47).  Against the same tower computing every row of every
     block, in every precision that has the path: equal to the precision's own rounding (the pooled row's softmax and P.V
     run in fp32, the full kernel rounds P to 16 bits) -- bf16x3 to 1e-5, fp16 to 2e-4, bf16 to 1.5e-3 -- deterministic, and
-    independent of the batch the image sits in (ragged batch sizes included).  ("tiny" at batch 1100: more rows than one
+    independent of the batch the image sits in (ragged batch sizes included).  (The QuickGELU config: the skinny GEMM's
+    finalize kernel and the tiled epilogues apply the same activation variant per precision -- ADVICE r03.)  ("tiny" at batch 1100: more rows than one
     skinny-GEMM launch takes -- they go through it in chunks of 1024, K slices depending on (N, K) only, so the pooled rows
     stay on the skinny path; width 128, so the residual stream is fp32.)"""
     cfg = configs.get_config(name)

@@ -566,20 +566,22 @@ def test_text_backward_every_sequence_length_class_vs_oracle_autograd(eng, preci
     assert rel_l2(gx, xr.grad) < (TOL if precision == "bf16x3" else 1e-2)  # measured 2.2e-3 .. 3.9e-3 (bf16), 4e-6 .. 6e-6 (bf16x3)
 
 
+@pytest.mark.parametrize("quick", [False, True])
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
-def test_text_tower_25_classes_all_tiles_k_split(eng, precision):
+def test_text_tower_25_classes_all_tiles_k_split(eng, precision, quick):
     """25 classes x 93 tokens = 2 325 rows of the ViT-B text tower: 10 row tiles, so every GEMM of a block has fewer tiles
     than half the CUs.  In split-bf16 all four are then K-split over the idle CUs (48 / 192 k-steps in parts of >= 16): QKV,
     out_proj, c_fc -- the fix-up kernel applies bias + exact-erf GELU and writes hi + lo planes -- and c_proj; in bf16 only
     c_proj is long enough (64 steps).  Hidden states against the CPU oracle of `clip.model.transformer(x)` (reference
     models/model_wrapper.py:58,72)."""
-    cfg = configs.get_config("ViT-B-16")
+    cfg = configs.get_config("ViT-B-16-quickgelu" if quick else "ViT-B-16")  # (QuickGELU: the fix-up kernel's activation variant, ADVICE r03)
     sd = synth.make_state_dict(cfg, seed=2, vision=False)
     tower = eng.TextTower(cfg, sd, DEV, precision)
     n, T, D = 25, 93, 512
     x = torch.cat([synth.normal([n, 16, D], 8, "ks.ctx"), synth.normal([n, 77, D], 8, "ks.tok", 0.02)], dim=1)
+    import dataclasses
     with torch.no_grad():
-        ref, _, _ = clip_ref.text_transformer_raw(x, sd, clip_ref.CONFIGS["ViT-B-16"])
+        ref, _, _ = clip_ref.text_transformer_raw(x, sd, dataclasses.replace(clip_ref.CONFIGS["ViT-B-16"], quick_gelu=quick))
     r = tower.forward(x.to(DEV), want_mean=True)
     _report(f"text tower 25 classes {precision} hidden", r["hidden"], ref)
     assert torch.isfinite(r["hidden"]).all()
