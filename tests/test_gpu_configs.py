@@ -28,7 +28,7 @@ import tap_clip_amd  # noqa: F401
 from conftest import golden, rel_l2, rel_max
 from oracle import clip_ref
 from tap_clip_amd import configs, synth
-from test_gpu_parity import DEV, TOL, TOL_BF16, TOL_TAIL_SPLIT, _build_full, _report
+from test_gpu_parity import DEV, TOL, TOL_BF16, TOL_TAIL_SPLIT, _bf16_floor, _build_full, _report
 
 pytestmark = pytest.mark.gpu
 
@@ -48,22 +48,24 @@ def test_fullmodel_vitb16_65_classes_vs_reference(semantics):
     g = golden(f"fullmodel_{semantics}_vitb16_c65")
     ref = torch.from_numpy(g["logits"])
     labels = torch.from_numpy(g["labels"]).to(DEV)
-    for precision, tol in (("bf16x3", TOL), ("fp16", TOL), ("bf16", TOL_BF16)):
+    fl = _bf16_floor(g, "ViT-B-16", semantics)  # the bf16 mode is held to 1.5x what the format itself costs on this case
+    for precision, tol in (("bf16x3", TOL), ("fp16", TOL), ("bf16", 1.5 * fl["logits"])):
         model, images = _build_full("ViT-B-16", g, semantics, precision)
         with torch.no_grad():
             out = model(images, labels)
         _report(f"FullModel ViT-B/16 65 classes {semantics} {precision} logits", out["logits"], ref)
         assert out["logits"].shape == (4, 65)
         assert rel_max(out["logits"].cpu(), ref) < tol
-        assert abs(float(out["loss"]) - float(g["loss"])) < tol * max(1.0, abs(float(g["loss"])))
+        assert abs(float(out["loss"]) - float(g["loss"])) < (max(1.5 * fl["loss"], 2e-3) if precision == "bf16" else tol * max(1.0, abs(float(g["loss"]))))
         if semantics == "intended":
+            tol_map = 1.5 * fl["map"] if precision == "bf16" else tol
             amap = model.clip.attention_maps[0].cpu()                        # pass 1's capture: [65, 93, 93]
             assert amap.shape == (65, 93, 93)
             _report(f"  head-mean map {precision}", amap[:8], torch.from_numpy(g["attn_map_head"]))
-            assert rel_max(amap[:8], torch.from_numpy(g["attn_map_head"])) < tol
-            assert rel_max(amap[:, :, -1], torch.from_numpy(g["attn_map_last_col"])) < tol
+            assert rel_max(amap[:8], torch.from_numpy(g["attn_map_head"])) < tol_map
+            assert rel_max(amap[:, :, -1], torch.from_numpy(g["attn_map_last_col"])) < tol_map
             assert torch.allclose(amap.sum(-1), torch.from_numpy(g["attn_row_sums"]), atol=1e-4)
-            assert rel_max(model.last_attribution.cpu(), torch.from_numpy(g["attribution"])) < tol
+            assert rel_max(model.last_attribution.cpu(), torch.from_numpy(g["attribution"])) < (max(1.5 * fl["attribution"], TOL) if precision == "bf16" else tol)
         if precision == "bf16x3":
             # the training step of the same model: context gradients of the reference's autograd
             model.train()

@@ -9,7 +9,8 @@ Tolerances (BASELINE.json north_star: 1e-3 relative):
                      two such pipelines cannot agree better than `clip_ref.emulation_floor` measures
                      (1.1e-3 rel-L2 / 3.0e-3 rel-max per ViT-B block); the block test bounds the kernels
                      at 1.5x that measured floor, rel-L2 and rel-max.
-  TOL_BF16   = 2e-2  plain bf16 vs the fp32 oracle: operand-quantisation noise of bf16 (8-bit
+  TOL_BF16   = 2e-2  (unit kernels; the FullModel tests against the reference's goldens use 1.5x the MEASURED cost of the format
+             instead: _bf16_floor)  plain bf16 vs the fp32 oracle: operand-quantisation noise of bf16 (8-bit
                      mantissa) through 12 layers; reported, bounded, not the parity claim.
 `rel_max` = max|a-b| / max|b|, `rel_l2` = ||a-b|| / ||b||.
 """
@@ -439,15 +440,45 @@ def test_fullmodel_tiny_vs_reference(semantics, precision):
         out = model(images, torch.from_numpy(g["labels"]).to(DEV))
     ref = torch.from_numpy(g["logits"])
     _report(f"FullModel tiny {semantics} {precision} logits", out["logits"], ref)
-    tol = TOL if precision == "bf16x3" else TOL_BF16
+    fl = _bf16_floor(g, "tiny", semantics) if precision == "bf16" else None
+    tol = TOL if fl is None else 1.5 * fl["logits"]
     assert rel_max(out["logits"].cpu(), ref) < tol
-    assert abs(float(out["loss"]) - float(g["loss"])) < tol * max(1.0, abs(float(g["loss"])))
+    assert abs(float(out["loss"]) - float(g["loss"])) < (TOL * max(1.0, abs(float(g["loss"]))) if fl is None else max(1.5 * fl["loss"], 2e-3))
     assert torch.equal(model.prompt_learner().cpu(), torch.from_numpy(g["prompts"]))
     if semantics == "intended":
-        assert rel_max(model.last_attribution.cpu(), torch.from_numpy(g["attribution"])) < tol
-        assert rel_max(model.clip.attention_maps[0].cpu(), torch.from_numpy(g["attn_map"])) < tol
+        assert rel_max(model.last_attribution.cpu(), torch.from_numpy(g["attribution"])) < (TOL if fl is None else max(1.5 * fl["attribution"], TOL))
+        assert rel_max(model.clip.attention_maps[0].cpu(), torch.from_numpy(g["attn_map"])) < (TOL if fl is None else 1.5 * fl["map"])
     keys = set(model.state_dict().keys())
     assert set(g["state_dict_keys"].tolist()) <= keys, sorted(set(g["state_dict_keys"].tolist()) - keys)[:5]
+
+
+def _bf16_floor(g, cfg_name, semantics):
+    """What bf16 OPERANDS cost FullModel's outputs on a golden case, measured instead of chosen ("a bound the builder
+    chose"): the CPU oracle with every MFMA operand rounded to bf16 at the kernels' rounding points (oracle/clip_ref.py `emulate`)
+    against the reference's own outputs.  The bf16 mode of the HIP towers is held to 1.5x these figures -- the two differ by
+    accumulation order and by which way ties of the chained roundings fall (clip_ref.emulation_floor)."""
+    from oracle import full_model_ref
+
+    cfg = clip_ref.CONFIGS[cfg_name]
+    hcfg = configs.get_config(cfg_name)
+    sd = synth.make_state_dict(hcfg, seed=int(g["seed_weights"]))
+    P, n = int(g["prompt_len"]), len(g["class_names"])
+    ctx = torch.from_numpy(g["context"]) if "context" in g.files else synth.make_prompts(n, P, hcfg, seed=int(g["seed_context"]))[0]
+    tok = sd["token_embedding.weight"][torch.from_numpy(g["token_ids"])]
+    images = synth.make_images(int(g["batch"]), hcfg, int(g["seed_images"]))
+    with torch.no_grad():
+        out = full_model_ref.forward_collapsed(images, torch.cat([ctx, tok], 1), P, sd, cfg, attn_semantics=semantics, emulate="bf16",
+                                               labels=torch.from_numpy(g["labels"]))
+    floor = {"logits": rel_max(out["logits"], torch.from_numpy(g["logits"])), "loss": abs(float(out["loss"]) - float(g["loss"]))}
+    if semantics == "intended":
+        amap = out["attn_map"]
+        if "attn_map" in g.files:
+            floor["map"] = rel_max(amap, torch.from_numpy(g["attn_map"]))
+        else:
+            floor["map"] = max(rel_max(amap[:8], torch.from_numpy(g["attn_map_head"])), rel_max(amap[:, :, -1], torch.from_numpy(g["attn_map_last_col"])))
+        floor["attribution"] = rel_max(out["attribution"], torch.from_numpy(g["attribution"]))
+    print("[parity] bf16 floor (emulating oracle vs the reference): " + ", ".join(f"{k} {v:.3e}" for k, v in floor.items()))
+    return floor
 
 
 def _oracle_context_grad(g, cfg_name, semantics, emulate):
@@ -639,13 +670,14 @@ def test_fullmodel_vitb32_cfg1_vs_reference(semantics):
     ref = torch.from_numpy(g["logits"])
     # fp16 = IEEE-half image tower (2.8e-4 on the embeddings) + split-bf16 text tower: the fast mode inside the 1e-3
     # bound, on logits too (round 1's IEEE-half text tower left these small-magnitude logits at 1.3e-3 rel-max)
-    for precision, tol in (("bf16x3", TOL), ("bf16", TOL_BF16), ("fp16", TOL)):
+    fl = _bf16_floor(g, "ViT-B-32", semantics)
+    for precision, tol in (("bf16x3", TOL), ("bf16", 1.5 * fl["logits"]), ("fp16", TOL)):
         model, images = _build_full("ViT-B-32", g, semantics, precision)
         with torch.no_grad():
             out = model(images, torch.from_numpy(g["labels"]).to(DEV))
         _report(f"FullModel ViT-B/32 cfg1 {semantics} {precision} logits", out["logits"], ref)
         assert rel_max(out["logits"].cpu(), ref) < tol
-        assert abs(float(out["loss"]) - float(g["loss"])) < tol * max(1.0, abs(float(g["loss"])))
+        assert abs(float(out["loss"]) - float(g["loss"])) < (max(1.5 * fl["loss"], 2e-3) if precision == "bf16" else tol * max(1.0, abs(float(g["loss"]))))
         assert torch.equal(out["logits"].argmax(1).cpu(), ref.argmax(1)) or precision == "bf16"
         del model
         torch.cuda.empty_cache()
