@@ -56,7 +56,7 @@ def test_fullmodel_vitb16_65_classes_vs_reference(semantics):
         _report(f"FullModel ViT-B/16 65 classes {semantics} {precision} logits", out["logits"], ref)
         assert out["logits"].shape == (4, 65)
         assert rel_max(out["logits"].cpu(), ref) < tol
-        assert abs(float(out["loss"]) - float(g["loss"])) < (max(1.5 * fl["loss"], 2e-3) if precision == "bf16" else tol * max(1.0, abs(float(g["loss"]))))
+        assert abs(float(out["loss"]) - float(g["loss"])) < (1.5 * fl["loss"] if precision == "bf16" else tol * max(1.0, abs(float(g["loss"]))))
         if semantics == "intended":
             tol_map = 1.5 * fl["map"] if precision == "bf16" else tol
             amap = model.clip.attention_maps[0].cpu()                        # pass 1's capture: [65, 93, 93]

@@ -443,7 +443,7 @@ def test_fullmodel_tiny_vs_reference(semantics, precision):
     fl = _bf16_floor(g, "tiny", semantics) if precision == "bf16" else None
     tol = TOL if fl is None else 1.5 * fl["logits"]
     assert rel_max(out["logits"].cpu(), ref) < tol
-    assert abs(float(out["loss"]) - float(g["loss"])) < (TOL * max(1.0, abs(float(g["loss"]))) if fl is None else max(1.5 * fl["loss"], 2e-3))
+    assert abs(float(out["loss"]) - float(g["loss"])) < (TOL * max(1.0, abs(float(g["loss"]))) if fl is None else 1.5 * fl["loss"])
     assert torch.equal(model.prompt_learner().cpu(), torch.from_numpy(g["prompts"]))
     if semantics == "intended":
         assert rel_max(model.last_attribution.cpu(), torch.from_numpy(g["attribution"])) < (TOL if fl is None else max(1.5 * fl["attribution"], TOL))
@@ -469,14 +469,18 @@ def _bf16_floor(g, cfg_name, semantics):
     with torch.no_grad():
         out = full_model_ref.forward_collapsed(images, torch.cat([ctx, tok], 1), P, sd, cfg, attn_semantics=semantics, emulate="bf16",
                                                labels=torch.from_numpy(g["labels"]))
-    floor = {"logits": rel_max(out["logits"], torch.from_numpy(g["logits"])), "loss": abs(float(out["loss"]) - float(g["loss"]))}
+    # (the loss: cross-entropy moves by at most twice the largest logit error -- bounded through the logits, not through the
+    # emulation's own loss error, which is a signed sum that may cancel)
+    floor = {"logits": rel_max(out["logits"], torch.from_numpy(g["logits"]))}
+    floor["loss"] = 2.0 * floor["logits"] * float(torch.from_numpy(g["logits"]).abs().max())
     if semantics == "intended":
         amap = out["attn_map"]
         if "attn_map" in g.files:
             floor["map"] = rel_max(amap, torch.from_numpy(g["attn_map"]))
-        else:
+        elif "attn_map_head" in g.files:
             floor["map"] = max(rel_max(amap[:8], torch.from_numpy(g["attn_map_head"])), rel_max(amap[:, :, -1], torch.from_numpy(g["attn_map_last_col"])))
-        floor["attribution"] = rel_max(out["attribution"], torch.from_numpy(g["attribution"]))
+        if "attribution" in g.files:
+            floor["attribution"] = rel_max(out["attribution"], torch.from_numpy(g["attribution"]))
     print("[parity] bf16 floor (emulating oracle vs the reference): " + ", ".join(f"{k} {v:.3e}" for k, v in floor.items()))
     return floor
 
@@ -677,7 +681,7 @@ def test_fullmodel_vitb32_cfg1_vs_reference(semantics):
             out = model(images, torch.from_numpy(g["labels"]).to(DEV))
         _report(f"FullModel ViT-B/32 cfg1 {semantics} {precision} logits", out["logits"], ref)
         assert rel_max(out["logits"].cpu(), ref) < tol
-        assert abs(float(out["loss"]) - float(g["loss"])) < (max(1.5 * fl["loss"], 2e-3) if precision == "bf16" else tol * max(1.0, abs(float(g["loss"]))))
+        assert abs(float(out["loss"]) - float(g["loss"])) < (1.5 * fl["loss"] if precision == "bf16" else tol * max(1.0, abs(float(g["loss"]))))
         assert torch.equal(out["logits"].argmax(1).cpu(), ref.argmax(1)) or precision == "bf16"
         del model
         torch.cuda.empty_cache()
