@@ -36,6 +36,50 @@ __device__ __forceinline__ bf16x8_t tr_pair(const uint8_t* base0, const uint8_t*
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// ---- softmax arithmetic of the three kernels below.  The score loop is VALU-issue bound (a flash step of 16 scores per lane was
+// 73 plain VALU ops + 17 v_exp_f32 beside 16 MFMAs), and a third of those ops were avoidable:
+//  * fmaxf() has IEEE maxNum semantics, so hipcc canonicalises every MFMA output in front of it (v_max_f32 x, x, x: one extra op
+//    per score); the raw v_max3_f32 folds two scores per instruction and needs none.  (NaN scores propagate differently --
+//    they do not occur: the operands are finite and masked scores are -inf.)
+//  * exp argument and row sum two scores at a time: v_pk_fma_f32 / v_pk_add_f32 issue in the time of the scalar op.  Plain
+//    operand order only (the [0,1] op_sel encodings are the ones tests/test_abi.py rejects).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ float fold_max(float m, const f32x4_t& v) { return max3_raw(max3_raw(m, v[0], v[1]), v[2], v[3]); }
+// sum2[0] + sum2[1] as ONE scalar add (left to itself hipcc forms v_pk_add_f32 vX, vX, vX op_sel:[0,1], the pair swap)
+__device__ __forceinline__ float pair_sum(f32x2_t v) {
+  float a = v[0];
+  asm("" : "+v"(a));
+  return a + v[1];
+}
+// v <- exp2(v * log2e + nmx) element-wise, sum2 += (v[0] + v[2], v[1] + v[3])
+#ifndef TAPCLIP_LEAN_PACKED
+#define TAPCLIP_LEAN_PACKED 0
+#endif
+template <bool PACKED = true>  // (false: the 80-VGPR instantiation -- aligned register pairs for every score cost it 3 more spilled dwords)
+__device__ __forceinline__ void exp_sum4(f32x4_t& v, float nmx, f32x2_t& sum2) {
+  if constexpr (!PACKED) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = __builtin_amdgcn_exp2f(fmaf(v[e], 1.44269504088896340736f, nmx));
+      sum2[0] += v[e];
+    }
+    return;
+  }
+  const f32x2_t l2 = {1.44269504088896340736f, 1.44269504088896340736f}, n2 = {nmx, nmx};
+  const f32x2_t a0 = __builtin_elementwise_fma(f32x2_t{v[0], v[1]}, l2, n2);
+  const f32x2_t a1 = __builtin_elementwise_fma(f32x2_t{v[2], v[3]}, l2, n2);
+  const f32x2_t p0 = {__builtin_amdgcn_exp2f(a0[0]), __builtin_amdgcn_exp2f(a0[1])};
+  const f32x2_t p1 = {__builtin_amdgcn_exp2f(a1[0]), __builtin_amdgcn_exp2f(a1[1])};
+  sum2 += p0;
+  sum2 += p1;
+  v = f32x4_t{p0[0], p0[1], p1[0], p1[1]};
+}
+
 // Stores of one query row's head slice: lane (r, g) holds O[q][16 g + 4 dt + e] / sum for dt = 0..3, i.e. 16
 // consecutive columns.  bf16: 32 bytes per lane.
 template <bool SPLIT>
@@ -242,20 +286,15 @@ __global__ __launch_bounds__(512, (NKT % 2) ? 6 : 1) void attn_kernel(AttnArgs a
         for (int e = 0; e < 4; ++e)
           if (4 * g + e == ((T - 1) & 15)) sc[kt][e] += a.last_key_bias;
       }
-      mx = fmaxf(mx, fmaxf(fmaxf(sc[kt][0], sc[kt][1]), fmaxf(sc[kt][2], sc[kt][3])));
+      mx = fold_max(mx, sc[kt]);
     }
     mx = rows_max(mx);
     const float LOG2E = 1.44269504088896340736f;
     const float nmx = -mx * LOG2E;
-    float sum = 0.f;
+    f32x2_t sum2 = {0.f, 0.f};
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(sc[kt][e], LOG2E, nmx));  // exp(s - max); 0 when masked
-        sc[kt][e] = p;
-        sum += p;
-      }
+    for (int kt = 0; kt < NKT; ++kt) exp_sum4<!LEAN || TAPCLIP_LEAN_PACKED>(sc[kt], nmx, sum2);  // exp(s - max); 0 when masked
+    float sum = pair_sum(sum2);
     sum = rows_sum(sum);
     const float inv = 1.0f / sum;
 
@@ -352,15 +391,31 @@ __global__ __launch_bounds__(512) void attn_flash_kernel(AttnArgs a) {
   const int64_t ld = 3 * (int64_t)D;
   const int qcol = head * 64, kcol = D + head * 64, vcol = 2 * D + head * 64;
   const int n_qt = (T + 15) >> 4;
-  const int qt0 = (blockIdx.y * 8 + wave) * QT;
+  // query tile t of this wave: the chunk's 8 QT tiles are dealt to the waves ROUND-ROBIN (tile = chunk base + 8 t + wave), so a
+  // ragged last chunk (T = 577: 37 tiles = 16 + 16 + 5) gives five waves ONE tile each and the workgroup lasts one tile time;
+  // dealt in runs of QT (waves 0, 1 two tiles, wave 2 one, the rest none) it lasted two with 2.5 of 8 waves busy
+  const int qt_base = blockIdx.y * 8 * QT + wave;
+  auto tile_of = [&](int t) { return qt_base + 8 * t; };
   const float LOG2E = 1.44269504088896340736f;
+#ifndef TAPCLIP_FLASH_ABL
+#define TAPCLIP_FLASH_ABL 0  // timing-only ablations (tools/Makefile attn_bench_alt): 1 no softmax VALU, 2 no MFMAs, 4 no LDS fragment reads, 8 no re-staging / barriers
+#endif
+  constexpr int ABL = TAPCLIP_FLASH_ABL;
+  auto mm = [](const bf16x8_t& x, const bf16x8_t& y, const f32x4_t& c) {
+    if constexpr ((ABL & 2) != 0) {
+      asm volatile("" ::"v"(x), "v"(y));
+      return c;
+    } else {
+      return TAPCLIP_MFMA_16x16x32(x, y, c);
+    }
+  };
 
   bf16x8_t qh[QT][2], ql[SPLIT ? QT : 1][2];
   float m[QT], l[QT];
   f32x4_t oc[QT][4];
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
-    int qc = (qt0 + t) * 16 + r;
+    int qc = tile_of(t) * 16 + r;
     if (qc >= T) qc = T - 1;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -408,13 +463,13 @@ __global__ __launch_bounds__(512) void attn_flash_kernel(AttnArgs a) {
   if (PREFETCH) fetch_block(0);
   for (int kb = 0; kb < n_kb; ++kb) {
     const int key_base = kb * KEYS;
-    __syncthreads();  // every wave is done reading the previous block
+    if (!(ABL & 8) || kb == 0) __syncthreads();  // every wave is done reading the previous block
     if (!PREFETCH) fetch_block(kb);
 #pragma unroll
     for (int it = 0; it < N_IT; ++it) {
       const int c = tid + 512 * it;
       const int kk = c >> 3, kc = c & 7;
-      if (kk >= KEYS) continue;
+      if (kk >= KEYS || ((ABL & 8) && kb > 0)) continue;
       const int ko = kk * 128 + ((kc ^ (kk & 7)) << 4);
       const int vs = (kk >> 1) & 3;  // quad swizzle of the V image, as in attn_kernel
       const int vo = kk * 128 + ((kc >> 1) << 5) + (((kc & 1) ^ (vs >> 1)) << 4);
@@ -425,13 +480,13 @@ __global__ __launch_bounds__(512) void attn_flash_kernel(AttnArgs a) {
         *reinterpret_cast<uint4*>(Vl + vo) = (vs & 1) ? make_uint4(vvlr[it].z, vvlr[it].w, vvlr[it].x, vvlr[it].y) : vvlr[it];
       }
     }
-    __syncthreads();
-    if (PREFETCH && kb + 1 < n_kb) fetch_block(kb + 1);  // in flight during the products below
+    if (!(ABL & 8) || kb == 0) __syncthreads();
+    if (PREFETCH && kb + 1 < n_kb && !(ABL & 8)) fetch_block(kb + 1);  // in flight during the products below
 
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-      if (qt0 + t >= n_qt) break;  // wave-uniform
-      const int qi = (qt0 + t) * 16 + r;
+      if (tile_of(t) >= n_qt) break;  // wave-uniform
+      const int qi = tile_of(t) * 16 + r;
       f32x4_t sc[KB];
 #pragma unroll
       for (int kt = 0; kt < KB; ++kt) {
@@ -440,15 +495,16 @@ __global__ __launch_bounds__(512) void attn_flash_kernel(AttnArgs a) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           const int off = kk * 128 + (((4 * s + g) ^ (kk & 7)) << 4);
-          const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Kh + off);
-          sc[kt] = TAPCLIP_MFMA_16x16x32(kf, qh[t][s], sc[kt]);
+          const bf16x8_t kf = (ABL & 4) ? qh[t][s] : *reinterpret_cast<const bf16x8_t*>(Kh + off);
+          sc[kt] = mm(kf, qh[t][s], sc[kt]);
           if (SPLIT) {
             const bf16x8_t kfl = *reinterpret_cast<const bf16x8_t*>(Kl + off);
-            sc[kt] = TAPCLIP_MFMA_16x16x32(kfl, qh[t][s], sc[kt]);
-            sc[kt] = TAPCLIP_MFMA_16x16x32(kf, ql[t][s], sc[kt]);
+            sc[kt] = mm(kfl, qh[t][s], sc[kt]);
+            sc[kt] = mm(kf, ql[t][s], sc[kt]);
           }
         }
       }
+      if constexpr ((ABL & 1) == 0) {
       float bm = -INFINITY;
 #pragma unroll
       for (int kt = 0; kt < KB; ++kt) {
@@ -459,28 +515,25 @@ __global__ __launch_bounds__(512) void attn_flash_kernel(AttnArgs a) {
             if (key >= T || (a.causal && key > qi)) sc[kt][e] = -INFINITY;
           }
         }
-        bm = fmaxf(bm, fmaxf(fmaxf(sc[kt][0], sc[kt][1]), fmaxf(sc[kt][2], sc[kt][3])));
+        bm = fold_max(bm, sc[kt]);
       }
       bm = rows_max(bm);
       const float m_new = fmaxf(m[t], bm);
       // m_new == -inf only while every key so far is masked (then p = 0 and nothing is accumulated)
       const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f((m[t] - m_new) * LOG2E);
       const float nmx = (m_new == -INFINITY) ? 0.0f : -m_new * LOG2E;
-      float bs = 0.f;
+      f32x2_t bs2 = {0.f, 0.f};
 #pragma unroll
-      for (int kt = 0; kt < KB; ++kt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(sc[kt][e], LOG2E, nmx));
-          sc[kt][e] = p;
-          bs += p;
-        }
-      l[t] = fmaf(l[t], alpha, bs);
+      for (int kt = 0; kt < KB; ++kt) {
+        exp_sum4(sc[kt], nmx, bs2);
+      }
+      l[t] = fmaf(l[t], alpha, pair_sum(bs2));
       m[t] = m_new;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) oc[t][dt][e] *= alpha;
+      }
 
 #pragma unroll
       for (int s2 = 0; s2 < KB / 2; ++s2) {
@@ -506,12 +559,12 @@ __global__ __launch_bounds__(512) void attn_flash_kernel(AttnArgs a) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           const int coff = (pp << 5) + ((dt ^ sw) << 3);
-          const bf16x8_t vf = tr_pair(Vh + key0 * 128 + coff, Vh + key1 * 128 + coff);
-          oc[t][dt] = TAPCLIP_MFMA_16x16x32(vf, ph, oc[t][dt]);
+          const bf16x8_t vf = (ABL & 4) ? ph : tr_pair(Vh + key0 * 128 + coff, Vh + key1 * 128 + coff);
+          oc[t][dt] = mm(vf, ph, oc[t][dt]);
           if (SPLIT) {
             const bf16x8_t vfl = tr_pair(Vl + key0 * 128 + coff, Vl + key1 * 128 + coff);
-            oc[t][dt] = TAPCLIP_MFMA_16x16x32(vfl, ph, oc[t][dt]);
-            oc[t][dt] = TAPCLIP_MFMA_16x16x32(vf, pl, oc[t][dt]);
+            oc[t][dt] = mm(vfl, ph, oc[t][dt]);
+            oc[t][dt] = mm(vf, pl, oc[t][dt]);
           }
         }
       }
@@ -520,8 +573,8 @@ __global__ __launch_bounds__(512) void attn_flash_kernel(AttnArgs a) {
 
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
-    if (qt0 + t >= n_qt) break;
-    const int qi = (qt0 + t) * 16 + r;
+    if (tile_of(t) >= n_qt) break;
+    const int qi = tile_of(t) * 16 + r;
     float sum = l[t];
     sum = rows_sum(sum);
     const float inv = 1.0f / sum;
