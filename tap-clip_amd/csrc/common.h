@@ -90,13 +90,37 @@ __device__ __forceinline__ uint32_t mx8_scale_byte(float amax) {  // amax >= 0
   return (uint32_t)(e < 0 ? 0 : e);  // zero / denormal blocks: 2^-127
 }
 __device__ __forceinline__ float mx8_inv_scale(uint32_t byte) { return __uint_as_float((254u - byte) << 23); }  // 2^(127 - byte)
+// a register with no defined content and no instruction behind it: both halves of a packed word are written by the two
+// conversions, so zeroing it first (what passing 0 as the old value costs: one v_mov per word) is wasted issue
+__device__ __forceinline__ int mx8_undef_word() {
+  int v;
+  asm("" : "=v"(v));
+  return v;
+}
 __device__ __forceinline__ uint32_t mx8_pack4(float a, float b, float c, float d, float inv) {
   a = __builtin_amdgcn_fmed3f(a * inv, -448.f, 448.f);
   b = __builtin_amdgcn_fmed3f(b * inv, -448.f, 448.f);
   c = __builtin_amdgcn_fmed3f(c * inv, -448.f, 448.f);
   d = __builtin_amdgcn_fmed3f(d * inv, -448.f, 448.f);
-  int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);  // bytes 0, 1 (round to nearest even, OCP e4m3 on gfx950)
-  v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);       // bytes 2, 3
+  int v = mx8_undef_word();
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);  // bytes 0, 1 (round to nearest even, OCP e4m3 on gfx950)
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);   // bytes 2, 3
+  return (uint32_t)v;
+}
+// max(m, |a|, |b|) in one op (fmaxf / fabsf on packed results no longer fuse into v_max3_f32 by themselves)
+__device__ __forceinline__ float amax3_raw(float m, float a, float b) {
+  float d;
+  asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(d) : "v"(m), "v"(a), "v"(b));
+  return d;
+}
+// the same on two pairs (the scale multiply as v_pk_mul_f32)
+typedef float f32x2_mx_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t mx8_pack4(f32x2_mx_t ab, f32x2_mx_t cd, float inv) {
+  ab = ab * f32x2_mx_t{inv, inv};
+  cd = cd * f32x2_mx_t{inv, inv};
+  int v = mx8_undef_word();
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(ab[0], -448.f, 448.f), __builtin_amdgcn_fmed3f(ab[1], -448.f, 448.f), v, false);
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(cd[0], -448.f, 448.f), __builtin_amdgcn_fmed3f(cd[1], -448.f, 448.f), v, true);
   return (uint32_t)v;
 }
 __device__ __forceinline__ size_t mx8_scale_index(int64_t row, int block, int64_t rows_pad) {
@@ -169,9 +193,71 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
   const float e = __builtin_amdgcn_exp2f(p * xc);
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
-// GELU of the 16-bit fast paths (bf16 and the IEEE-half build): the fit above.  (The erf form in the half build
-// changed nothing measurable -- cfg-1 logits 1.3e-3 -> 1.7e-3 rel-max, same 9.8e-4 rel-L2 -- and cost 40 us per c_fc.)
-__device__ __forceinline__ float gelu_fast16(float x) { return gelu_erf_fast(x); }
+// Transcendental-free GELU (round 4):  gelu(x) = max(x, 0) + f(min(|x|, 4.5)),  f(t) = gelu(t) - t = -t Phi(-t)  -- a smooth bump
+// (-0.17 at t = 0.75) with a Gaussian tail, -1.5e-5 at the clamp -- by a degree-10 polynomial in u = t / 2.25 - 1 (Chebyshev-range
+// variable: coefficients below 0.44, Horner in fp32 loses nothing).  Max |error| against the exact-erf form 1.44e-5 over all x
+// (the sigmoid fit above: 2.5e-5).  Cost per PAIR of values: 2 v_min (|x| is a source modifier), 1 + 10 v_pk_fma_f32, 2 v_max,
+// 1 v_pk_add_f32 = 8 issue slots per value against 12 for the fit (whose v_exp_f32 / v_rcp_f32 are quarter rate).
+#ifndef TAPCLIP_GELU_FORM
+#define TAPCLIP_GELU_FORM 0  // 0: the sigmoid fit, packed (default); 1: this polynomial; 2: the sigmoid fit, scalar (A/B only)
+#endif
+typedef float f32x2_pk_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_pk_t gelu_poly2(f32x2_pk_t x) {
+  f32x2_pk_t t, r;
+  // raw v_min / v_max: fminf / fmaxf would first canonicalise the MFMA output (one more VALU op per value)
+  asm("v_min_f32_e64 %0, |%1|, %2" : "=v"(t[0]) : "v"(x[0]), "v"(4.5f));
+  asm("v_min_f32_e64 %0, |%1|, %2" : "=v"(t[1]) : "v"(x[1]), "v"(4.5f));
+  asm("v_max_f32_e32 %0, 0, %1" : "=v"(r[0]) : "v"(x[0]));
+  asm("v_max_f32_e32 %0, 0, %1" : "=v"(r[1]) : "v"(x[1]));
+  const f32x2_pk_t u = __builtin_elementwise_fma(t, f32x2_pk_t{0.44444445f, 0.44444445f}, f32x2_pk_t{-1.0f, -1.0f});
+  constexpr float C[11] = {-2.749713324e-02f, 1.330395043e-01f, -2.465924025e-01f, 1.472157985e-01f, 2.029682845e-01f, -4.347813427e-01f,
+                           2.049071938e-01f,  1.763149798e-01f, -1.763803661e-01f, -2.178246900e-02f, 4.258675873e-02f};
+  f32x2_pk_t p = {C[10], C[10]};
+#pragma unroll
+  for (int k = 9; k >= 0; --k) p = __builtin_elementwise_fma(p, u, f32x2_pk_t{C[k], C[k]});
+  return r + p;
+}
+__device__ __forceinline__ float gelu_poly(float x) { return gelu_poly2(f32x2_pk_t{x, x})[0]; }  // (same op sequence: same bits)
+// gelu_erf_fast on a PAIR of values with the plain ops packed (v_pk_mul / v_pk_fma / v_pk_add_f32: the same roundings, the same
+// bits as the scalar form): 2 v_med3 + 6 packed ops + 2 v_exp + 2 v_rcp = 6 issue slots per value instead of 8.5.
+__device__ __forceinline__ f32x2_pk_t gelu_erf_fast2(f32x2_pk_t x) {
+  const f32x2_pk_t xc = {__builtin_amdgcn_fmed3f(x[0], -10.0f, 10.0f), __builtin_amdgcn_fmed3f(x[1], -10.0f, 10.0f)};
+  const f32x2_pk_t x2 = xc * xc;
+  f32x2_pk_t p = __builtin_elementwise_fma(f32x2_pk_t{1.0142631e-3f, 1.0142631e-3f}, x2, f32x2_pk_t{-1.0677573e-1f, -1.0677573e-1f});
+  p = __builtin_elementwise_fma(p, x2, f32x2_pk_t{-2.3011213f, -2.3011213f});
+  const f32x2_pk_t a = p * xc;
+  const f32x2_pk_t d = f32x2_pk_t{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])} + f32x2_pk_t{1.0f, 1.0f};
+  return x * f32x2_pk_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+// QuickGELU, packed the same way (bits of gelu_quick_fast below)
+__device__ __forceinline__ f32x2_pk_t gelu_quick_fast2(f32x2_pk_t x) {
+  constexpr float K = -1.702f * 1.4426950408889634f;
+  const f32x2_pk_t a = f32x2_pk_t{K, K} * x;
+  const f32x2_pk_t d = f32x2_pk_t{1.0f, 1.0f} + f32x2_pk_t{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+  return x * f32x2_pk_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+// GELU of the 16-bit fast paths (bf16 and the IEEE-half build).  (The erf form in the half build changed nothing measurable --
+// cfg-1 logits 1.3e-3 -> 1.7e-3 rel-max, same 9.8e-4 rel-L2 -- and cost 40 us per c_fc.)
+__device__ __forceinline__ float gelu_fast16(float x) { return TAPCLIP_GELU_FORM == 1 ? gelu_poly(x) : gelu_erf_fast(x); }
+template <typename V4>
+__device__ __forceinline__ void gelu_quick_fast_x4(V4& v) {
+  const f32x2_pk_t a = gelu_quick_fast2(f32x2_pk_t{v[0], v[1]}), b = gelu_quick_fast2(f32x2_pk_t{v[2], v[3]});
+  v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+}
+// four values of an accumulator at once (the tiled GEMMs' epilogues)
+template <typename V4>
+__device__ __forceinline__ void gelu_fast16_x4(V4& v) {
+  if (TAPCLIP_GELU_FORM == 1) {
+    const f32x2_pk_t a = gelu_poly2(f32x2_pk_t{v[0], v[1]}), b = gelu_poly2(f32x2_pk_t{v[2], v[3]});
+    v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+  } else if (TAPCLIP_GELU_FORM == 0) {
+    const f32x2_pk_t a = gelu_erf_fast2(f32x2_pk_t{v[0], v[1]}), b = gelu_erf_fast2(f32x2_pk_t{v[2], v[3]});
+    v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_fast(v[e]);
+  }
+}
 // derivatives (backward of c_fc's activation); the bf16 forward uses the fitted GELU, whose derivative
 // differs from the exact one by < 2e-4
 __device__ __forceinline__ float gelu_erf_grad(float x) {

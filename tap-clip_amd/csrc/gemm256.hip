@@ -336,8 +336,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
         for (int j = 0; j < NJ; ++j) {
           f32x4_t v = acc[j][i];
           if (EPI == EPI_BIAS_GELU_BF16) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ACT == 0 ? gelu_fast16(v[e]) : ACT == 1 ? gelu_quick_fast(v[e]) : v[e];
+            if (ACT == 0) gelu_fast16_x4(v);
+            if (ACT == 1) gelu_quick_fast_x4(v);
           }
           const unsigned long long pk = (unsigned long long)pack_bf2(v[0], v[1]) | ((unsigned long long)pack_bf2(v[2], v[3]) << 32);
           const int chunk = 2 * j + (q >> 1);
@@ -384,10 +384,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
           for (int J = 0; J < 2; ++J) {
             f32x4_t v0 = acc[2 * J][i], v1 = acc[2 * J + 1][i];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v0[e] = ACT == 0 ? gelu_fast16(v0[e]) : ACT == 1 ? gelu_quick_fast(v0[e]) : v0[e];
-              v1[e] = ACT == 0 ? gelu_fast16(v1[e]) : ACT == 1 ? gelu_quick_fast(v1[e]) : v1[e];
+            if (ACT == 0) {
+              gelu_fast16_x4(v0);
+              gelu_fast16_x4(v1);
+            }
+            if (ACT == 1) {
+              gelu_quick_fast_x4(v0);
+              gelu_quick_fast_x4(v1);
             }
             pk[J][0] = pack_bf2(v0[0], v0[1]);
             pk[J][1] = pack_bf2(v0[2], v0[3]);
@@ -425,10 +428,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
           for (int J = 0; J < NJ / 2; ++J) {
             f32x4_t v0 = acc[2 * J][i], v1 = acc[2 * J + 1][i];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v0[e] = ACT == 0 ? gelu_fast16(v0[e]) : ACT == 1 ? gelu_quick_fast(v0[e]) : v0[e];
-              v1[e] = ACT == 0 ? gelu_fast16(v1[e]) : ACT == 1 ? gelu_quick_fast(v1[e]) : v1[e];
+            if (ACT == 0) {
+              gelu_fast16_x4(v0);
+              gelu_fast16_x4(v1);
+            }
+            if (ACT == 1) {
+              gelu_quick_fast_x4(v0);
+              gelu_quick_fast_x4(v1);
             }
             u32x4_t pk;
             pk[0] = pack_bf2(v0[0], v0[1]);

@@ -320,21 +320,23 @@ __global__ __launch_bounds__(512) void gemm_mx8_kernel(Mx8GemmArgs g) {
         u32x4_t val[2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float y[32];
+          // (pairs: the activation's plain ops and the scale multiply issue as packed fp32 ops -- same roundings, same bits --
+          // 12.5 -> 9 VALU issue slots per value; the epilogue is VALU-bound)
+          f32x2_pk_t y[16];
           float amax = 0.f;
 #pragma unroll
-          for (int e = 0; e < 32; ++e) {
-            const float x = acc[e >> 4][i][e & 15];
-            y[e] = ACT == 0 ? gelu_erf_fast(x) : ACT == 1 ? gelu_quick_fast(x) : x;
-            amax = fmaxf(amax, fabsf(y[e]));
+          for (int e = 0; e < 16; ++e) {
+            const f32x2_pk_t x = {acc[e >> 3][i][(2 * e) & 15], acc[e >> 3][i][(2 * e + 1) & 15]};
+            y[e] = ACT == 0 ? gelu_erf_fast2(x) : ACT == 1 ? gelu_quick_fast2(x) : x;
+            amax = amax3_raw(amax, y[e][0], y[e][1]);
           }
           const uint32_t byte = mx8_scale_byte(amax);
           const float inv = mx8_inv_scale(byte);
           u32x4_t p0, p1;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            p0[e] = mx8_pack4(y[4 * e], y[4 * e + 1], y[4 * e + 2], y[4 * e + 3], inv);
-            p1[e] = mx8_pack4(y[16 + 4 * e], y[16 + 4 * e + 1], y[16 + 4 * e + 2], y[16 + 4 * e + 3], inv);
+            p0[e] = mx8_pack4(y[2 * e], y[2 * e + 1], inv);
+            p1[e] = mx8_pack4(y[8 + 2 * e], y[8 + 2 * e + 1], inv);
           }
           if (full || m0 + wm * 128 + 32 * i + r < g.M) sptr[64 * i] = (uint8_t)byte;
 #pragma unroll

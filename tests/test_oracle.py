@@ -255,6 +255,29 @@ def test_emulation_floor_of_chained_bf16_rounding():
     assert 3e-4 < l2["out"] < 2e-3 and 1e-3 < floor["out"][1] < 6e-3
 
 
+def test_polynomial_gelu_variant_is_within_its_stated_bound():
+    """csrc/common.h also carries a transcendental-free GELU (TAPCLIP_GELU_FORM=1, not the default: DESIGN section 4 "Round 4 (j)"):
+    max(x, 0) + P(min(|x|, 4.5) * 0.4444 - 1), P of degree 10.  Its header states 1.44e-5 against the exact-erf form; the
+    coefficients are read from the header and evaluated in fp32 Horner form here."""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tap-clip_amd", "csrc", "common.h")).read()
+    m = re.search(r"constexpr float C\[11\] = \{([^}]*)\}", src)
+    assert m, "polynomial GELU coefficients not found in common.h"
+    co = [np.float32(v.strip().rstrip("f")) for v in m.group(1).split(",")]
+    assert len(co) == 11
+    x = np.concatenate([np.linspace(-12, 12, 1200001), np.random.default_rng(0).normal(size=200000) * 2]).astype(np.float32)
+    u = (np.minimum(np.abs(x), np.float32(4.5)).astype(np.float64) * np.float64(np.float32(0.44444445)) - 1.0).astype(np.float32)
+    acc = np.full_like(u, co[10])
+    for k in range(9, -1, -1):
+        acc = (acc.astype(np.float64) * u + np.float64(co[k])).astype(np.float32)  # fma: one rounding
+    y = np.maximum(x, 0) + acc
+    exact = torch.nn.functional.gelu(torch.from_numpy(x).double()).numpy()
+    err = np.abs(y.astype(np.float64) - exact).max()
+    print(f"polynomial GELU max abs err {err:.3e}")
+    assert err < 1.5e-5
+
+
 def test_fitted_gelu_is_within_its_stated_bound_of_the_exact_form():
     """The 16-/8-bit fast paths apply x * sigmoid(x * (a + b x^2 + c x^4)) (csrc/common.h gelu_erf_fast, restated as
     clip_ref.gelu_fit), and `emulate` uses the same constants -- so emulate-vs-kernel comparisons do not check the
