@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collects the round's profile set on the GPU box (run through gpurun from the repo root), in two parts (a gpurun call is
 # limited to 20 minutes):
-#   tools/collect_profiles.sh <tag> main    bench line, rocprofv3 kernel stats, PMC traffic (bf16 headline AND the fp16 parity
-#                                           mode) and SQ counters of the ViT-B/16 headline
+#   tools/collect_profiles.sh <tag> main    rocprofv3 kernel stats, PMC traffic (bf16 headline AND the fp16 parity mode) and SQ
+#                                           counters of the ViT-B/16 headline, then the bench line itself
 #   tools/collect_profiles.sh <tag> vitl    BASELINE configs[4] at its per-GPU size in fp8 / bf16 / fp16 (seeded host weights)
 # -> gpurun_out/prof_<tag>/..., summaries copied by hand into profiles/
 set -e
@@ -14,8 +14,6 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 FAST="--steps 3 --warmup 1 --no-cpu-baseline --no-full-forward --no-kernel-events --no-precisions --no-input-side --no-configs4"
 if [ $PART = main ]; then
-python3 $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
-echo "bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $R/bench.py --no-configs4 > $OUT/bench_under_trace.json 2> $OUT/stats.err
 echo "trace done"
 for P in bf16 fp16; do
@@ -32,6 +30,12 @@ python3 tools/pmc_traffic.py $OUT/fetch $OUT/write $OUT/pmc_traffic_bench.json
 python3 tools/pmc_traffic.py $OUT/fetch_fp16 $OUT/write_fp16 $OUT/pmc_traffic_bench_fp16.json
 python3 tools/pmc_sq.py $OUT/sq $OUT/pmc_sq_bench.json
 cp $(ls $OUT/stats/*kernel_stats.csv $OUT/stats/*/*kernel_stats.csv 2>/dev/null | head -n 1) $OUT/kernel_stats_bench.csv
+# the bench line LAST, with this box's PMC summaries in place (in the box's scratch copy of the repo): `roofline.traffic` is only
+# reported when the summary's recorded source hash equals the running library's, and so the line and the counters are of one box
+cp $OUT/pmc_traffic_bench.json $R/profiles/${TAG}_pmc_traffic_bench.json
+cp $OUT/pmc_traffic_bench_fp16.json $R/profiles/${TAG}_pmc_traffic_bench_fp16.json
+python3 $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+echo "bench done"
 # the raw traces are large: keep the summaries only
 rm -rf $OUT/stats/*/*kernel_trace.csv $OUT/stats/*kernel_trace.csv $OUT/fetch $OUT/write $OUT/fetch_fp16 $OUT/write_fp16 $OUT/sq
 echo "summaries done"
