@@ -1,0 +1,179 @@
+// Check + interleaved timing of the long-sequence (T > 256) attention kernels at the ViT-L/14@336 shape (development tool; not
+// part of the library).  Build: make -C tools attn_bench.  Usage: tools/attn_bench [n_seq=128] [rounds=12] [cfg cfg ...]
+//   cfg: 1 = the first flash kernel (attention.hip attn_flash_kernel), WAVES * 10 + QT = a geometry of the second (42, 82, ...)
+// The check: softmax(q k^T) v in double on the host for a few (sequence, head) pairs, from the same 16-bit q|k|v.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../tap-clip_amd/csrc/kernels.h"
+
+using namespace tapclip;
+
+#define CK(x)                                                                       \
+  do {                                                                              \
+    hipError_t e_ = (x);                                                            \
+    if (e_ != hipSuccess) {                                                         \
+      printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      exit(1);                                                                      \
+    }                                                                               \
+  } while (0)
+
+#ifdef TAPCLIP_FP16
+static float h2f(uint16_t b) {
+  _Float16 h;
+  memcpy(&h, &b, 2);
+  return (float)h;
+}
+#else
+static float h2f(uint16_t b) {
+  uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+#endif
+
+// q|k|v rows: approximately normal entries (sum of four uniforms), written as the library's 16-bit operand type
+__global__ void fill_kernel(uint16_t* p, size_t n, float scale, uint32_t seed) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    uint64_t s = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
+    float acc = 0.f;
+    for (int k = 0; k < 4; ++k) {
+      s ^= s >> 33; s *= 0xff51afd7ed558ccdull; s ^= s >> 33; s *= 0xc4ceb9fe1a85ec53ull; s ^= s >> 29;
+      acc += (float)(s & 0xFFFFFF) / 16777216.0f - 0.5f;
+    }
+    const float v = acc * 1.7320508f * scale;  // variance scale^2
+#ifdef TAPCLIP_FP16
+    _Float16 h = (_Float16)v;
+    uint16_t b;
+    memcpy(&b, &h, 2);
+    p[i] = b;
+#else
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    u += 0x7FFF + ((u >> 16) & 1);
+    p[i] = (uint16_t)(u >> 16);
+#endif
+  }
+}
+
+int main(int argc, char** argv) {
+  const int n_seq = argc > 1 ? atoi(argv[1]) : 128;
+  const int rounds = argc > 2 ? atoi(argv[2]) : 12;
+  std::vector<int> cfgs;
+  for (int i = 3; i < argc; ++i) cfgs.push_back(atoi(argv[i]));
+  if (cfgs.empty()) cfgs = {1, 0};
+  const int T = getenv("ATTN_BENCH_T") ? atoi(getenv("ATTN_BENCH_T")) : 577, H = 16, D = 1024;
+  const float scale = getenv("ATTN_BENCH_SCALE") ? (float)atof(getenv("ATTN_BENCH_SCALE")) : 0.6f;  // q.k sigma = 64^0.5 scale^2 = 2.9
+  const size_t rows = (size_t)n_seq * T;
+  uint16_t *qkv, *out;
+  CK(hipMalloc(&qkv, rows * 3 * D * 2));
+  CK(hipMalloc(&out, rows * D * 2));
+  hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, qkv, rows * 3 * D, scale, 12345u);
+  CK(hipDeviceSynchronize());
+  hipStream_t s;
+  CK(hipStreamCreate(&s));
+  AttnArgs a;
+  a.qkv_hi = qkv; a.qkv_lo = nullptr; a.out_hi = out; a.out_lo = nullptr; a.probs = nullptr;
+  a.n_seq = n_seq; a.T = T; a.H = H; a.D = D; a.causal = 0;
+
+  // ---- check: pairs (first, middle, last sequence) x (heads 0, 7, 15), every query row
+  const int seqs[3] = {0, n_seq / 2, n_seq - 1}, heads[3] = {0, 7, 15};
+  std::vector<uint16_t> hq((size_t)T * 3 * D), ho((size_t)T * D);
+  std::vector<double> ref((size_t)9 * T * 64);
+  for (int si = 0; si < 3; ++si) {
+    CK(hipMemcpy(hq.data(), qkv + (size_t)seqs[si] * T * 3 * D, hq.size() * 2, hipMemcpyDeviceToHost));
+    for (int hi = 0; hi < 3; ++hi) {
+      const int h = heads[hi];
+      std::vector<double> p(T);
+      for (int q = 0; q < T; ++q) {
+        double mx = -1e300;
+        for (int k = 0; k < T; ++k) {
+          double sc = 0;
+          for (int d = 0; d < 64; ++d) sc += (double)h2f(hq[(size_t)q * 3 * D + h * 64 + d]) * (double)h2f(hq[(size_t)k * 3 * D + D + h * 64 + d]);
+          p[k] = sc;
+          mx = std::max(mx, sc);
+        }
+        double sum = 0;
+        for (int k = 0; k < T; ++k) { p[k] = std::exp(p[k] - mx); sum += p[k]; }
+        for (int d = 0; d < 64; ++d) {
+          double o = 0;
+          for (int k = 0; k < T; ++k) o += p[k] * (double)h2f(hq[(size_t)k * 3 * D + 2 * D + h * 64 + d]);
+          ref[((size_t)(si * 3 + hi) * T + q) * 64 + d] = o / sum;
+        }
+      }
+    }
+  }
+  bool ok = true;
+  for (int cfg : cfgs) {
+    flash2_set_cfg(cfg);
+    CK(hipMemsetAsync(out, 0xFF, rows * D * 2, s));  // NaN patterns: an unwritten element shows
+    CK(launch_attention(a, false, s));
+    CK(hipStreamSynchronize(s));
+    double max_err = 0, sum_sq = 0, ref_sq = 0;
+    for (int si = 0; si < 3; ++si) {
+      CK(hipMemcpy(ho.data(), out + (size_t)seqs[si] * T * D, ho.size() * 2, hipMemcpyDeviceToHost));
+      for (int hi = 0; hi < 3; ++hi)
+        for (int q = 0; q < T; ++q)
+          for (int d = 0; d < 64; ++d) {
+            const double g = h2f(ho[(size_t)q * D + heads[hi] * 64 + d]), r = ref[((size_t)(si * 3 + hi) * T + q) * 64 + d];
+            const double e = std::fabs(g - r);
+            if (!(e == e)) max_err = 1e30;
+            max_err = std::max(max_err, e);
+            sum_sq += e * e;
+            ref_sq += r * r;
+          }
+    }
+    // every element of the whole output written and finite
+    std::vector<uint16_t> all(rows * D);
+    CK(hipMemcpy(all.data(), out, all.size() * 2, hipMemcpyDeviceToHost));
+    size_t bad = 0;
+    for (size_t i = 0; i < all.size(); ++i) {
+      const float f = h2f(all[i]);
+      if (!(f == f) || std::fabs(f) > 1e4f) {
+        if (bad < 6) printf("   bad: seq %zu token %zu head %zu d %zu bits %04x\n", i / D / T, (i / D) % T, (i % D) / 64, i % 64, all[i]);
+        ++bad;
+      }
+    }
+    const double rel = std::sqrt(sum_sq / ref_sq);
+    printf("cfg %3d: check vs fp64 host softmax: max abs err %.3e  rel-L2 %.3e  non-finite/unwritten %zu\n", cfg, max_err, rel, bad);
+    if (rel > 8e-3 || bad) ok = false;
+  }
+
+  // ---- timing: interleaved rounds, one untimed + four timed launches per configuration and round
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  std::vector<std::vector<float>> t(cfgs.size());
+  flash2_set_cfg(cfgs[0]);
+  for (int w = 0; w < 200; ++w) CK(launch_attention(a, false, s));  // clocks settle
+  CK(hipStreamSynchronize(s));
+  for (int round = 0; round < rounds; ++round)
+    for (size_t c = 0; c < cfgs.size(); ++c) {
+      flash2_set_cfg(cfgs[c]);
+      CK(launch_attention(a, false, s));
+      CK(hipEventRecord(e0, s));
+      for (int i = 0; i < 4; ++i) CK(launch_attention(a, false, s));
+      CK(hipEventRecord(e1, s));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      t[c].push_back(ms / 4);
+    }
+  const double fl = 4.0 * n_seq * H * (double)T * T * 64.0;
+  for (size_t c = 0; c < cfgs.size(); ++c) {
+    std::sort(t[c].begin(), t[c].end());
+    const double med = t[c][t[c].size() / 2], mn = t[c][0];
+    printf("cfg %3d  n%d T%d H%d: median %8.1f us %7.1f TFLOP/s   min %8.1f us\n", cfgs[c], n_seq, T, H, 1e3 * med, fl / (med * 1e-3) / 1e12, 1e3 * mn);
+  }
+  printf(ok ? "CHECK OK\n" : "CHECK FAILED\n");
+  return ok ? 0 : 1;
+}
