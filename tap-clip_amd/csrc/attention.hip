@@ -22,6 +22,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "attn_store.h"
 
 namespace tapclip {
 namespace {
@@ -78,62 +79,6 @@ __device__ __forceinline__ void exp_sum4(f32x4_t& v, float nmx, f32x2_t& sum2) {
   sum2 += p0;
   sum2 += p1;
   v = f32x4_t{p0[0], p0[1], p1[0], p1[1]};
-}
-
-// Stores of one query row's head slice: lane (r, g) holds O[q][16 g + 4 dt + e] / sum for dt = 0..3, i.e. 16
-// consecutive columns.  bf16: 32 bytes per lane.
-template <bool SPLIT>
-__device__ __forceinline__ void store_o_bf16(const AttnArgs& a, const f32x4_t (&oc)[4], float inv, int64_t row, int head, int g) {
-  const int64_t off = row * a.D + head * 64 + 16 * g;
-  uint32_t wh[8], wl[8];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) {
-    if (SPLIT) {
-      bf16_t h[4], l[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) split_bf(oc[dt][e] * inv, h[e], l[e]);
-      wh[2 * dt] = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
-      wh[2 * dt + 1] = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
-      wl[2 * dt] = (uint32_t)l[0] | ((uint32_t)l[1] << 16);
-      wl[2 * dt + 1] = (uint32_t)l[2] | ((uint32_t)l[3] << 16);
-    } else {
-      wh[2 * dt] = pack_bf2(oc[dt][0] * inv, oc[dt][1] * inv);
-      wh[2 * dt + 1] = pack_bf2(oc[dt][2] * inv, oc[dt][3] * inv);
-    }
-  }
-  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-  u32x4_t* dh = reinterpret_cast<u32x4_t*>(a.out_hi + off);
-  // (non-temporal stores make this kernel faster ALONE -- 73.3 -> 67.6 us in tools/gemm_bench -- and slower in the
-  // tower, 79 -> 85 us with out_proj + 1.5 us behind it: there the output buffer is cache-resident from the previous
-  // block and its consumer reads it from the cache.  Plain stores.)
-  dh[0] = u32x4_t{wh[0], wh[1], wh[2], wh[3]};
-  dh[1] = u32x4_t{wh[4], wh[5], wh[6], wh[7]};
-  if (SPLIT) {
-    u32x4_t* dl = reinterpret_cast<u32x4_t*>(a.out_lo + off);
-    dl[0] = u32x4_t{wl[0], wl[1], wl[2], wl[3]};
-    dl[1] = u32x4_t{wl[4], wl[5], wl[6], wl[7]};
-  }
-}
-// MXFP8: the head's 64 columns are two 32-blocks, block b held by the lanes g = 2 b, 2 b + 1 of the row.  Called by
-// all lanes (the shuffle needs them); `valid` masks the stores.
-__device__ __forceinline__ void store_o_mx8(const AttnArgs& a, const f32x4_t (&oc)[4], float inv, int64_t row, int head, int g,
-                                            bool valid) {
-  float am = 0.f;
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) am = fmaxf(am, fabsf(oc[dt][e] * inv));
-  am = xor16_max(am);
-  const uint32_t byte = mx8_scale_byte(am);
-  if (!valid) return;
-  const float is = mx8_inv_scale(byte);
-  uint4 pk;
-  pk.x = mx8_pack4(oc[0][0] * inv, oc[0][1] * inv, oc[0][2] * inv, oc[0][3] * inv, is);
-  pk.y = mx8_pack4(oc[1][0] * inv, oc[1][1] * inv, oc[1][2] * inv, oc[1][3] * inv, is);
-  pk.z = mx8_pack4(oc[2][0] * inv, oc[2][1] * inv, oc[2][2] * inv, oc[2][3] * inv, is);
-  pk.w = mx8_pack4(oc[3][0] * inv, oc[3][1] * inv, oc[3][2] * inv, oc[3][3] * inv, is);
-  *reinterpret_cast<uint4*>(a.out_q + row * a.D + head * 64 + 16 * g) = pk;
-  if ((g & 1) == 0) a.out_q_scale[((size_t)head * a.out_m_pad + row) * 2 + (g >> 1)] = (uint8_t)byte;
 }
 
 template <int NKT, bool SPLIT, bool TIED = false>  // TIED: the last key counts exp(last_key_bias) times (tied.hip) -- its own
@@ -628,338 +573,6 @@ hipError_t launch_flash(const AttnArgs& a, hipStream_t s) {
   return kb == 4 ? launch_flash_q<SPLIT, 2, 4>(a, s) : kb == 6 ? launch_flash_q<SPLIT, 2, 6>(a, s) : launch_flash_q<SPLIT, 2, 8>(a, s);
 }
 
-// ---- long sequences, second generation (round 5): the 16-bit (non-split, non-causal) path of T > 256.
-// What the ablation of the kernel above showed (profiles/r04_flash_attention_ablation.txt: 97 of 164 us were neither VALU nor
-// MFMA) and what its traffic looked like decide the shape:
-//  * K/V blocks (64 keys) go global -> LDS by LDS-DMA into a ring of NS stages, ONE barrier per block, the DMA of block
-//    j + NS - 1 in flight under the products of block j -- no staging registers, no second barrier, no LDS store issue.
-//    The DMA writes lane-linear 1-KiB pieces (8 key rows), so both images are swizzled on the SOURCE side at 16-byte
-//    granularity: K position p of row k holds chunk p ^ (k & 7) (conflict-free ds_read_b128 of the A fragments), V position p
-//    holds chunk p ^ ((k >> 1) & 3).  The transposed V reads stay conflict-free at that granularity because address lane pp of
-//    product dt takes the d-quad 4 pp + (dt ^ (pp & 1)): the two halves of every 16-byte chunk are read by different lanes of
-//    one instruction (the 8-byte swizzle of the kernels above cannot be produced by a 16-byte DMA).  A lane still ends up with
-//    16 consecutive d of its query -- lanes with odd g hold them with products 0 <-> 1, 2 <-> 3 exchanged (undone at the store).
-//  * ALL the query tiles of a wave (QT) use each K / V fragment read: with one tile per read (16 KB of LDS reads per 16 MFMAs)
-//    the LDS array ran at the MFMA pipe's own rate.
-//  * the row sums of P come from the matrix pipe (an all-ones A fragment: one MFMA per 32 keys and tile) instead of 16 VALU adds
-//    per lane: the loop is VALU-issue bound (16 exp + ~50 plain ops per tile and block beside 16 MFMAs), the matrix pipe is not.
-//    They are the sums of the ROUNDED probabilities, i.e. of exactly what multiplies V.
-//  * grid: the query chunks of one (sequence, head) sit 8 workgroup ids apart -- same XCD under round-robin placement,
-//    dispatched together -- so the later reads of a head's K/V are L2 hits (dim3(pairs, chunks) put them n_seq * H ids apart:
-//    every chunk re-read its 148 KB from HBM / Infinity Cache).
-//  * the last key block is run with as many 16-key tiles as it holds (577 = 9 x 64 + 1: one tile instead of four).
-//  * LAZY > 0: the running maximum of a query moves only when a block's maximum exceeds it by more than LAZY (in log2 units;
-//    un-normalised probabilities then reach 2^LAZY instead of 1 -- the same relative precision in a floating-point P, and
-//    65504 is far away), so the O accumulators are rescaled in the first block and after that almost never.
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void gbl_void_t;
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-#ifndef TAPCLIP_FLASH2_LAZY
-#define TAPCLIP_FLASH2_LAZY 8
-#endif
-#ifndef TAPCLIP_FLASH2_ABL
-#define TAPCLIP_FLASH2_ABL 0  // timing-only ablations (tools/Makefile attn_bench_alt): 1 no softmax VALU, 2 no MFMAs, 4 no LDS fragment reads, 8 no DMA / barriers after the first block
-#endif
-#ifndef TAPCLIP_FLASH2_KAHEAD
-#define TAPCLIP_FLASH2_KAHEAD 1  // K fragment reads in flight ahead of their products, in key tiles (1 .. 3)
-#endif
-__device__ __forceinline__ f32x4_t f2mm(const bf16x8_t& x, const bf16x8_t& y, const f32x4_t& c) {
-  if constexpr ((TAPCLIP_FLASH2_ABL & 2) != 0) {
-    asm volatile("" ::"v"(x), "v"(y));
-    return c;
-  } else {
-    return TAPCLIP_MFMA_16x16x32(x, y, c);
-  }
-}
-
-struct Flash2Lane {
-  int k_off0;  // K fragment reads: row r, chunk (g | 4 s) ^ (r & 7): s = 1 is this offset ^ 64
-  int v_off0;  // V transposed reads of product dt: row 4 g + qq, chunk ((2 pp + (dt >> 1)) ^ kappa), half (dt ^ pp) & 1: this offset ^ (16 (dt >> 1) | 8 (dt & 1))
-  int g;
-};
-
-// one key block (NKT 16-key tiles) for the NQ query tiles of a wave
-template <int QT, int NQ, int NKT, bool MASK>
-__device__ __forceinline__ void flash2_step(const uint8_t* Kb, const uint8_t* Vb, const Flash2Lane& ln, const bf16x8_t (&qh)[QT][2],
-                                            f32x4_t (&oc)[QT][4], float (&m)[QT], float (&l)[QT], int key_base, int T) {
-  constexpr float LOG2E = 1.44269504088896340736f;
-  constexpr int LAZY = TAPCLIP_FLASH2_LAZY;
-  f32x4_t sc[NQ][NKT];
-  {
-    // K fragments KA key tiles ahead of their products (the scheduler, left alone, hoists all eight reads: 32 registers)
-    constexpr int KA = TAPCLIP_FLASH2_KAHEAD < NKT ? TAPCLIP_FLASH2_KAHEAD : NKT;
-    constexpr int ABL = TAPCLIP_FLASH2_ABL;
-    bf16x8_t kf[KA + 1][2];
-    auto kread = [&](int kt, int slot) {
-      if constexpr ((ABL & 4) != 0) {
-        kf[slot][0] = qh[0][0];
-        kf[slot][1] = qh[0][1];
-      } else {
-        kf[slot][0] = *reinterpret_cast<const bf16x8_t*>(Kb + ln.k_off0 + kt * 2048);
-        kf[slot][1] = *reinterpret_cast<const bf16x8_t*>(Kb + (ln.k_off0 ^ 64) + kt * 2048);
-      }
-    };
-#pragma unroll
-    for (int kt = 0; kt < KA; ++kt) kread(kt, kt);
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      if (kt + KA < NKT) kread(kt + KA, (kt + KA) % (KA + 1));
-#pragma unroll
-      for (int t = 0; t < NQ; ++t) {
-        sc[t][kt] = f2mm(kf[kt % (KA + 1)][0], qh[t][0], (f32x4_t{0.f, 0.f, 0.f, 0.f}));
-        sc[t][kt] = f2mm(kf[kt % (KA + 1)][1], qh[t][1], sc[t][kt]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  const bf16_t one = f2bf(1.0f);
-  const s16x8_t ov = {(short)one, (short)one, (short)one, (short)one, (short)one, (short)one, (short)one, (short)one};
-  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ov);
-  bf16x8_t ph[NQ][(NKT + 1) / 2];
-#pragma unroll
-  for (int t = 0; t < NQ; ++t) {
-    float bm = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      if (MASK) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (key_base + kt * 16 + 4 * ln.g + e >= T) sc[t][kt][e] = -INFINITY;
-      }
-      bm = fold_max(bm, sc[t][kt]);
-    }
-    if constexpr ((TAPCLIP_FLASH2_ABL & 1) != 0) bm = 0.f;
-    else bm = rows_max(bm);  // finite: every block holds at least one key of the sequence
-    // (m starts at -inf: the first block always moves it; alpha = exp2(-inf) = 0 meets zeros)
-    if (LAZY == 0 || __builtin_amdgcn_ballot_w64(bm * LOG2E > m[t] * LOG2E + (float)LAZY) != 0) {  // wave-uniform
-      const float m_new = fmaxf(m[t], bm);
-      const float alpha = __builtin_amdgcn_exp2f((m[t] - m_new) * LOG2E);
-      m[t] = m_new;
-      l[t] *= alpha;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) oc[t][dt][e] *= alpha;
-    }
-    const float nmx = -m[t] * LOG2E;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if constexpr ((TAPCLIP_FLASH2_ABL & 1) == 0) sc[t][kt][e] = __builtin_amdgcn_exp2f(fmaf(sc[t][kt][e], LOG2E, nmx));
-#pragma unroll
-    for (int s2 = 0; s2 < (NKT + 1) / 2; ++s2) {
-      bf16_t h[8];
-#pragma unroll
-      for (int jj = 0; jj < 8; ++jj) h[jj] = (2 * s2 + (jj >> 2) < NKT) ? f2bf(sc[t][(2 * s2 + (jj >> 2)) < NKT ? 2 * s2 + (jj >> 2) : 0][jj & 3]) : (bf16_t)0;
-      const s16x8_t hv = {(short)h[0], (short)h[1], (short)h[2], (short)h[3], (short)h[4], (short)h[5], (short)h[6], (short)h[7]};
-      ph[t][s2] = __builtin_bit_cast(bf16x8_t, hv);
-    }
-    // row sum of the block on the matrix pipe: every row of A is ones, so every element of the result is the query's sum
-    f32x4_t bs = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s2 = 0; s2 < (NKT + 1) / 2; ++s2) bs = f2mm(ones, ph[t][s2], bs);
-    l[t] += bs[0];
-  }
-  {
-    // V fragments one product ahead, as above.  (NKT = 1: the upper half of the k range multiplies zeros into a re-read of
-    // the same four keys)
-    constexpr int NP = 4 * ((NKT + 1) / 2);
-    auto vread = [&](int i) {
-      const int s2 = i >> 2, dt = i & 3;
-      const uint8_t* vp = Vb + (ln.v_off0 ^ (16 * (dt >> 1) + 8 * (dt & 1))) + s2 * 4096;
-      if constexpr ((TAPCLIP_FLASH2_ABL & 4) != 0) return qh[0][dt & 1];
-      else return tr_pair(vp, vp + ((2 * s2 + 1 < NKT) ? 2048 : 0));
-    };
-    bf16x8_t vf[2];
-    vf[0] = vread(0);
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      if (i + 1 < NP) vf[(i + 1) & 1] = vread(i + 1);
-#pragma unroll
-      for (int t = 0; t < NQ; ++t) oc[t][i & 3] = f2mm(vf[i & 1], ph[t][i >> 2], oc[t][i & 3]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-}
-
-struct Flash2Ctx {
-  const uint8_t* qkv8;
-  int64_t row0_bytes;  // byte offset of the sequence's first q|k|v row
-  int64_t ld_bytes;
-  int k_src, v_src;    // byte offset inside a row of this lane's K / V source chunk
-  int drow;            // row of the lane inside its 8-row piece
-  int wave, T;
-};
-
-template <int WAVES, int QT, int NS, int NQ>
-__device__ __forceinline__ void flash2_run(const AttnArgs& a, uint8_t* smem, const Flash2Ctx& cx, const Flash2Lane& ln, const bf16x8_t (&qh)[QT][2],
-                                           int tile0, int64_t row0, int head, int r) {
-  constexpr int STAGE = 16384;     // [64 keys][128 B] K image | the same for V
-  constexpr int PPW = 8 / WAVES;   // 1-KiB pieces of K (and of V) per wave and block
-  const int T = cx.T;
-  auto dma_block = [&](int kb, int slot) {
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int piece = cx.wave + WAVES * i;
-      int key = kb * 64 + piece * 8 + cx.drow;
-      key = key < T ? key : T - 1;  // rows past the sequence: a copy of its last row (masked keys; finite V against P = 0)
-      const uint8_t* src = cx.qkv8 + cx.row0_bytes + (int64_t)key * cx.ld_bytes;
-      uint8_t* dst = smem + slot * STAGE + piece * 1024;
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + cx.k_src), (lds_void_t*)dst, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + cx.v_src), (lds_void_t*)(dst + 8192), 16, 0, 0);
-    }
-  };
-  float m[QT], l[QT];
-  f32x4_t oc[QT][4];
-#pragma unroll
-  for (int t = 0; t < QT; ++t) {
-    m[t] = -INFINITY;
-    l[t] = 0.f;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) oc[t][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  }
-
-  const int n_kb = (T + 63) >> 6, n_full = T >> 6;
-#pragma unroll
-  for (int i = 0; i < NS - 1; ++i)
-    if (i < n_kb) dma_block(i, i);
-  int slot = 0;
-  for (int kb = 0; kb < n_kb; ++kb) {
-    // block kb has landed once at most the blocks issued after it (2 PPW DMA instructions each) are outstanding
-    if (!(TAPCLIP_FLASH2_ABL & 8) || kb == 0) {
-      const int later = (n_kb - 1 - kb) < (NS - 2) ? (n_kb - 1 - kb) : (NS - 2);
-      if (later <= 0 || (TAPCLIP_FLASH2_ABL & 8)) wait_vm<0>();
-      else if (later == 1) wait_vm<2 * PPW>();
-      else wait_vm<2 * PPW * (NS > 3 ? 2 : 1)>();
-      __builtin_amdgcn_s_barrier();  // every wave's pieces of block kb are in LDS; every wave is done with block kb - 1
-      asm volatile("" ::: "memory");
-    }
-    if (kb + NS - 1 < n_kb && !(TAPCLIP_FLASH2_ABL & 8)) dma_block(kb + NS - 1, slot == 0 ? NS - 1 : slot - 1);  // into the slot of block kb - 1
-    const uint8_t* Kb = smem + slot * STAGE;
-    const uint8_t* Vb = Kb + 8192;
-    if constexpr (NQ > 0) {
-      if (kb < n_full) {
-        flash2_step<QT, NQ, 4, false>(Kb, Vb, ln, qh, oc, m, l, kb * 64, T);
-      } else {
-        const int rem = T - kb * 64;  // 1 .. 63 keys
-        if (rem <= 16) flash2_step<QT, NQ, 1, true>(Kb, Vb, ln, qh, oc, m, l, kb * 64, T);
-        else if (rem <= 32) flash2_step<QT, NQ, 2, true>(Kb, Vb, ln, qh, oc, m, l, kb * 64, T);
-        else flash2_step<QT, NQ, 4, true>(Kb, Vb, ln, qh, oc, m, l, kb * 64, T);
-      }
-    }
-    slot = slot + 1 == NS ? 0 : slot + 1;
-  }
-#pragma unroll
-  for (int t = 0; t < NQ; ++t) {
-    const int qi = (tile0 + WAVES * t) * 16 + r;
-    const float inv = 1.0f / l[t];
-    // lanes with odd g hold their 16 consecutive d with products 0 <-> 1 and 2 <-> 3 exchanged
-    f32x4_t oo[4];
-    const bool odd = (ln.g & 1) != 0;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) oo[dt][e] = odd ? oc[t][dt ^ 1][e] : oc[t][dt][e];
-    if (a.out_q != nullptr) store_o_mx8(a, oo, inv, row0 + qi, head, ln.g, qi < T);
-    else if (qi < T) store_o_bf16<false>(a, oo, inv, row0 + qi, head, ln.g);
-  }
-}
-
-// WAVES waves per workgroup, QT query tiles per wave (a chunk = WAVES * QT * 16 queries), WPS = waves per SIMD the build is
-// held to (register budget 512 / WPS)
-template <int WAVES, int QT, int NS, int WPS>
-__global__ __launch_bounds__(WAVES * 64, WPS) void attn_flash2_kernel(AttnArgs a, int chunks) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 15, g = lane >> 4;
-  const int T = a.T, D = a.D;
-  // workgroup id -> ((sequence, head), query chunk): the chunks of a pair are 8 ids apart
-  const int per = 8 * chunks;
-  const int grp = blockIdx.x / per, rem = blockIdx.x - grp * per;
-  const int pair = grp * 8 + (rem & 7), chunk = rem >> 3;
-  if (pair >= a.n_seq * a.H) return;  // (whole workgroup: the grid is rounded up to 8 pairs)
-  const int seq = pair / a.H, head = pair - seq * a.H;
-  const int64_t row0 = (int64_t)seq * T;
-  const int64_t ld = 3 * (int64_t)D;
-  const int qcol = head * 64, kcol = D + head * 64, vcol = 2 * D + head * 64;
-  const int n_qt = (T + 15) >> 4;
-  const int tile0 = chunk * (WAVES * QT) + wave;  // round-robin deal: tiles tile0, tile0 + WAVES, ...
-  int nq = 0;                                     // wave-uniform
-#pragma unroll
-  for (int t = 0; t < QT; ++t) nq += (tile0 + WAVES * t < n_qt) ? 1 : 0;
-
-  bf16x8_t qh[QT][2];
-#pragma unroll
-  for (int t = 0; t < QT; ++t) {
-    int qc = (tile0 + WAVES * t) * 16 + r;
-    if (qc >= T) qc = T - 1;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) qh[t][s] = *reinterpret_cast<const bf16x8_t*>(a.qkv_hi + (row0 + qc) * ld + qcol + 32 * s + 8 * g);
-  }
-
-  // the Q fragments are consumed HERE as far as the compiler's wait-count pass can tell: left pending, their first use inside
-  // the key loop gets an s_waitcnt vmcnt(0) that also drains the block DMAs issued behind them, in every iteration
-#pragma unroll
-  for (int t = 0; t < QT; ++t) asm volatile("" ::"v"(qh[t][0]), "v"(qh[t][1]));
-
-  Flash2Ctx cx;
-  cx.qkv8 = reinterpret_cast<const uint8_t*>(a.qkv_hi);
-  cx.row0_bytes = row0 * ld * 2;
-  cx.ld_bytes = ld * 2;
-  cx.drow = lane >> 3;
-  cx.k_src = kcol * 2 + (((lane & 7) ^ cx.drow) << 4);
-  cx.v_src = vcol * 2 + (((lane & 7) ^ ((cx.drow >> 1) & 3)) << 4);
-  cx.wave = wave;
-  cx.T = T;
-
-  Flash2Lane ln;
-  ln.g = g;
-  ln.k_off0 = r * 128 + ((g ^ (r & 7)) << 4);
-  const int qq = r >> 2, pp = r & 3;
-  const int kappa = 2 * (g & 1) + (qq >> 1);  // ((4 g + qq) >> 1) & 3
-  ln.v_off0 = (4 * g + qq) * 128 + (((2 * pp) ^ kappa) << 4) + ((pp & 1) << 3);
-
-  if (nq == QT) flash2_run<WAVES, QT, NS, QT>(a, smem, cx, ln, qh, tile0, row0, head, r);
-  else if (QT > 1 && nq == 1) flash2_run<WAVES, QT, NS, 1>(a, smem, cx, ln, qh, tile0, row0, head, r);
-  else if (QT > 2 && nq == 2) flash2_run<WAVES, QT, NS, (QT > 2 ? 2 : 0)>(a, smem, cx, ln, qh, tile0, row0, head, r);
-  else if (QT > 3 && nq == 3) flash2_run<WAVES, QT, NS, (QT > 3 ? 3 : 0)>(a, smem, cx, ln, qh, tile0, row0, head, r);
-  else flash2_run<WAVES, QT, NS, 0>(a, smem, cx, ln, qh, tile0, row0, head, r);
-}
-
-template <int WAVES, int QT, int NS, int WPS>
-hipError_t launch_flash2_cfg(const AttnArgs& a, hipStream_t s) {
-  constexpr int smem_bytes = NS * 16384;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash2_kernel<WAVES, QT, NS, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  const int n_qt = (a.T + 15) / 16;
-  const int chunks = (n_qt + WAVES * QT - 1) / (WAVES * QT);
-  const int pairs8 = (a.n_seq * a.H + 7) / 8;
-  hipLaunchKernelGGL((attn_flash2_kernel<WAVES, QT, NS, WPS>), dim3((unsigned)(pairs8 * 8 * chunks)), dim3(WAVES * 64), smem_bytes, s, a, chunks);
-  return hipGetLastError();
-}
-
-int g_flash2_cfg = -1;  // -1: not read yet; 0: default; 1: the first flash kernel; WAVES * 10 + QT pins a geometry
-hipError_t launch_flash2(const AttnArgs& a, hipStream_t s) {
-  switch (g_flash2_cfg) {
-    case 42: return launch_flash2_cfg<4, 2, 3, 3>(a, s);
-    case 43: return launch_flash2_cfg<4, 3, 3, 2>(a, s);
-    case 22: return launch_flash2_cfg<2, 2, 3, 3>(a, s);
-    case 24: return launch_flash2_cfg<2, 4, 3, 1>(a, s);
-    case 83: return launch_flash2_cfg<8, 3, 3, 2>(a, s);
-    default: return launch_flash2_cfg<4, 2, 3, 3>(a, s);
-  }
-}
-
 template <int NKT, bool SPLIT, bool TIED>
 hipError_t launch_tt(const AttnArgs& a, hipStream_t s) {
   static bool attr_set = false;
@@ -1133,8 +746,6 @@ __global__ __launch_bounds__(256) void attn_pool_kernel(AttnPoolArgs a) {
 
 }  // namespace
 
-void flash2_set_cfg(int cfg) { g_flash2_cfg = cfg; }  // tools/attn_bench: switch geometries inside one process
-
 hipError_t launch_attention_pooled(const bf16_t* q_hi, const bf16_t* q_lo, const bf16_t* qkv_hi, const bf16_t* qkv_lo, bf16_t* out_hi,
                                    bf16_t* out_lo, int32_t n_seq, int32_t T, int32_t H, int32_t D, bool split, hipStream_t s) {
   if (T <= 0 || T > POOL_MAX_T || D != H * 64 || n_seq <= 0 || !q_hi || !qkv_hi || !out_hi) return hipErrorInvalidValue;
@@ -1153,11 +764,7 @@ hipError_t launch_attention(const AttnArgs& a, bool split, hipStream_t s) {
   if (a.T > 256 || (force_flash && a.probs == nullptr && a.last_key_bias == 0.f)) {  // whole-head-in-LDS kernel holds at most 256 keys: flash-style kernel (no probability write-back)
     if (a.probs != nullptr) return hipErrorInvalidValue;
     // 16-bit operands without a mask: the LDS-DMA kernel (round 5); split-bf16 and causal stay on the first flash kernel
-    if (g_flash2_cfg < 0) {  // TAPCLIP_FLASH2_CFG (A/B, tools/attn_bench): 1 = the first flash kernel, WAVES * 10 + QT = a geometry
-      const char* e = getenv("TAPCLIP_FLASH2_CFG");
-      g_flash2_cfg = e ? atoi(e) : 0;
-    }
-    if (!split && !a.causal && g_flash2_cfg != 1) return launch_flash2(a, s);
+    if (!split && !a.causal && flash2_cfg() != 1) return launch_flash2(a, s);  // attention_long.hip
     return split ? launch_flash<true>(a, s) : launch_flash<false>(a, s);
   }
   return split ? dispatch<true>(a, s) : dispatch<false>(a, s);

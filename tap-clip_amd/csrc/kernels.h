@@ -133,7 +133,10 @@ struct AttnArgs {
   unsigned long long* stamps = nullptr;  // diagnostic builds only (-DATTN_STAMP, tools/): [workgroup][8] s_memrealtime stamps
 };
 hipError_t launch_attention(const AttnArgs& a, bool split, hipStream_t s);
-void flash2_set_cfg(int cfg);  // tools only: 0 default, 1 the first flash kernel, WAVES * 10 + QT a geometry of the second
+// attention_long.hip: T > 256, 16-bit operands, no mask (launch_attention routes there)
+hipError_t launch_flash2(const AttnArgs& a, hipStream_t s);
+int flash2_cfg();                // TAPCLIP_FLASH2_CFG: 0 default, 1 the first flash kernel, WAVES * 10 + QT a geometry of the second
+void flash2_set_cfg(int cfg);    // tools only
 // softmax(q K^T) V for ONE query row per sequence (the pooled token of a tower's last block): q [n_seq, D] (hi [+ lo]),
 // k / v taken from the q|k|v buffer [n_seq * T, 3 D] at columns D + 64 h / 2 D + 64 h, out [n_seq, D]
 hipError_t launch_attention_pooled(const bf16_t* q_hi, const bf16_t* q_lo, const bf16_t* qkv_hi, const bf16_t* qkv_lo, bf16_t* out_hi,

@@ -144,8 +144,24 @@ int main(int argc, char** argv) {
       }
     }
     const double rel = std::sqrt(sum_sq / ref_sq);
-    printf("cfg %3d: check vs fp64 host softmax: max abs err %.3e  rel-L2 %.3e  non-finite/unwritten %zu\n", cfg, max_err, rel, bad);
-    if (rel > 8e-3 || bad) ok = false;
+    // the whole output against the first configuration's (both are deterministic: differences beyond the 16-bit rounding of
+    // two summation orders mean corrupted operands somewhere the nine checked pairs do not look)
+    static std::vector<uint16_t> first;
+    double max_diff = 0;
+    size_t far = 0;
+    if (first.empty()) first = all;
+    else
+      for (size_t i = 0; i < all.size(); ++i) {
+        const double dd = std::fabs((double)h2f(all[i]) - (double)h2f(first[i]));
+        if (dd > max_diff) max_diff = dd;
+        if (dd > 0.03) {
+          if (far < 4) printf("   far: seq %zu token %zu head %zu d %zu: %g vs %g\n", i / D / T, (i / D) % T, (i % D) / 64, i % 64, h2f(all[i]), h2f(first[i]));
+          ++far;
+        }
+      }
+    printf("cfg %3d: check vs fp64 host softmax: max abs err %.3e  rel-L2 %.3e  non-finite/unwritten %zu | vs first cfg: max diff %.3e, %zu beyond 0.03\n", cfg,
+           max_err, rel, bad, max_diff, far);
+    if (rel > 8e-3 || bad || far) ok = false;
   }
 
   // ---- timing: interleaved rounds, one untimed + four timed launches per configuration and round
