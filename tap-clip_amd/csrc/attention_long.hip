@@ -55,6 +55,13 @@ __device__ __forceinline__ void wait_vm() {
 #ifndef TAPCLIP_FLASH2_ABL
 #define TAPCLIP_FLASH2_ABL 0  // timing-only ablations (tools/Makefile attn_bench_alt): 1 no softmax VALU, 2 no MFMAs, 4 no LDS fragment reads, 8 no DMA / barriers after the first block
 #endif
+#ifndef TAPCLIP_FLASH2_PRESCALE
+#define TAPCLIP_FLASH2_PRESCALE 0  // (off: the extra rounding of q doubles the kernel's error against fp64 -- bf16 1.96e-3 -> 3.72e-3, half 2.2e-4 -> 4.6e-4 -- for 4 % of its time; exact only if log2(e) were folded into Wq at pack time)
+// 1: the Q fragments carry log2(e) and the score accumulators start at -m: exp2 takes the MFMA output as it is
+#endif
+#ifndef TAPCLIP_FLASH2_VAHEAD
+#define TAPCLIP_FLASH2_VAHEAD 1  // V fragments in flight ahead of their products (1 .. 3 of the 4 or 8 per step)
+#endif
 #ifndef TAPCLIP_FLASH2_KAHEAD
 #define TAPCLIP_FLASH2_KAHEAD 1  // K fragment reads in flight ahead of their products, in key tiles (1 .. 3)
 #endif
@@ -103,7 +110,7 @@ __device__ __forceinline__ float flash2_tile_max(const f32x4_t (&sc)[NKT]) {
 // one key block (NKT 16-key tiles) for the NQ query tiles of a wave
 template <int QT, int NQ, int NKT, bool MASK>
 __device__ __forceinline__ void flash2_step(const uint8_t* Kb, const uint8_t* Vb, const Flash2Lane& ln, const bf16x8_t (&qh)[QT][2],
-                                            f32x4_t (&oc)[QT][4], float (&m)[QT], float (&l)[QT], int key_base, int T) {
+                                            f32x4_t (&oc)[QT][4], float (&m)[QT], float (&l)[QT], f32x4_t (&nm)[QT], int key_base, int T, bool first) {
   constexpr float LOG2E = 1.44269504088896340736f;
   constexpr int LAZY = TAPCLIP_FLASH2_LAZY;
   f32x4_t sc[NQ][NKT];
@@ -128,7 +135,7 @@ __device__ __forceinline__ void flash2_step(const uint8_t* Kb, const uint8_t* Vb
       if (kt + KA < NKT) kread(kt + KA, (kt + KA) % (KA + 1));
 #pragma unroll
       for (int t = 0; t < NQ; ++t) {
-        sc[t][kt] = f2mm(kf[kt % (KA + 1)][0], qh[t][0], (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+        sc[t][kt] = f2mm(kf[kt % (KA + 1)][0], qh[t][0], TAPCLIP_FLASH2_PRESCALE ? nm[t] : (f32x4_t{0.f, 0.f, 0.f, 0.f}));
         sc[t][kt] = f2mm(kf[kt % (KA + 1)][1], qh[t][1], sc[t][kt]);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -150,6 +157,33 @@ __device__ __forceinline__ void flash2_step(const uint8_t* Kb, const uint8_t* Vb
     float bm;
     if constexpr ((TAPCLIP_FLASH2_ABL & 1) != 0) bm = 0.f;
     else bm = flash2_tile_max<NKT>(sc[t]);  // finite: every block holds at least one key of the sequence
+    if constexpr (TAPCLIP_FLASH2_PRESCALE != 0) {
+      // scores arrive as (q . k) log2e - m log2e (m[] holds m log2e, nm[] its negative as the accumulators' start; both 0 before
+      // the first block): bm is the block's maximum RELATIVE to the running one.  It moves -- and everything held at the old
+      // maximum is rescaled, once -- in the first block and whenever it would be exceeded by more than LAZY.
+      if (first || LAZY == 0 || __builtin_amdgcn_ballot_w64(bm > (float)LAZY) != 0) {  // wave-uniform
+        const float up = first ? bm : fmaxf(bm, 0.f);
+        m[t] += up;
+        if (!first) {  // (first block: l and O are zeros, and exp2(-bm) may overflow)
+          const float alpha = __builtin_amdgcn_exp2f(-up);
+          l[t] *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) oc[t][dt][e] *= alpha;
+        }
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sc[t][kt][e] -= up;
+        nm[t] = f32x4_t{-m[t], -m[t], -m[t], -m[t]};
+      }
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if constexpr ((TAPCLIP_FLASH2_ABL & 1) == 0) sc[t][kt][e] = __builtin_amdgcn_exp2f(sc[t][kt][e]);
+    } else {
     // (m starts at -inf: the first block always moves it; alpha = exp2(-inf) = 0 meets zeros)
     if (LAZY == 0 || __builtin_amdgcn_ballot_w64(bm * LOG2E > m[t] * LOG2E + (float)LAZY) != 0) {  // wave-uniform
       const float m_new = fmaxf(m[t], bm);
@@ -167,6 +201,7 @@ __device__ __forceinline__ void flash2_step(const uint8_t* Kb, const uint8_t* Vb
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if constexpr ((TAPCLIP_FLASH2_ABL & 1) == 0) sc[t][kt][e] = __builtin_amdgcn_exp2f(fmaf(sc[t][kt][e], LOG2E, nmx));
+    }
 #pragma unroll
     for (int s2 = 0; s2 < (NKT + 1) / 2; ++s2) {
       bf16_t h[8];
@@ -195,32 +230,41 @@ __device__ __forceinline__ void flash2_step(const uint8_t* Kb, const uint8_t* Vb
     uint32_t va[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) va[dt] = vb + (uint32_t)(ln.v_off0 ^ (16 * (dt >> 1) + 8 * (dt & 1)));
-    u32x2_t lo[2], hi[2];
+    constexpr int VA = TAPCLIP_FLASH2_VAHEAD < NP ? TAPCLIP_FLASH2_VAHEAD : NP - 1;
+    u32x2_t lo[VA + 1], hi[VA + 1];
     auto vissue = [&](int i) {
-      const int s2 = i >> 2, dt = i & 3;
+      const int s2 = i >> 2, dt = i & 3, b = i % (VA + 1);
       if constexpr ((TAPCLIP_FLASH2_ABL & 4) == 0) {
         if (s2 == 0) {
-          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[i & 1]) : "v"(va[dt]));
-          if (NKT > 1) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(hi[i & 1]) : "v"(va[dt]));
-          else asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi[i & 1]) : "v"(va[dt]));
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[b]) : "v"(va[dt]));
+          if (NKT > 1) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(hi[b]) : "v"(va[dt]));
+          else asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi[b]) : "v"(va[dt]));
         } else {
-          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(lo[i & 1]) : "v"(va[dt]));
-          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(hi[i & 1]) : "v"(va[dt]));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(lo[b]) : "v"(va[dt]));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(hi[b]) : "v"(va[dt]));
         }
       } else {
-        lo[i & 1] = u32x2_t{va[dt], va[dt]};
-        hi[i & 1] = lo[i & 1];
+        lo[b] = u32x2_t{va[dt], va[dt]};
+        hi[b] = lo[b];
       }
     };
-    vissue(0);
+#pragma unroll
+    for (int i = 0; i < VA; ++i) vissue(i);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      if (i + 1 < NP) vissue(i + 1);
+      if (i + VA < NP) vissue(i + VA);
+      const int b = i % (VA + 1);
       if constexpr ((TAPCLIP_FLASH2_ABL & 4) == 0) {
-        if (i + 1 < NP) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(lo[i & 1]), "+v"(hi[i & 1]));
-        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[i & 1]), "+v"(hi[i & 1]));
+        // fragment i has landed once at most the reads issued after it are outstanding: two per fragment, min(VA, NP - 1 - i) fragments
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int later = (NP - 1 - i) < VA ? (NP - 1 - i) : VA;
+        if (later >= 3) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(lo[b]), "+v"(hi[b]));
+        else if (later == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(lo[b]), "+v"(hi[b]));
+        else if (later == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(lo[b]), "+v"(hi[b]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[b]), "+v"(hi[b]));
       }
-      const u32x4_t v4 = {lo[i & 1][0], lo[i & 1][1], hi[i & 1][0], hi[i & 1][1]};
+      const u32x4_t v4 = {lo[b][0], lo[b][1], hi[b][0], hi[b][1]};
       const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, v4);
 #pragma unroll
       for (int t = 0; t < NQ; ++t) oc[t][i & 3] = f2mm(vf, ph[t][i >> 2], oc[t][i & 3]);
@@ -249,36 +293,55 @@ __device__ __forceinline__ void wait_vm_rt(int n) {
   }
 }
 
-template <int WAVES, int QT, int NS, int NQ>
+template <int WAVES, int QT, int NS, int KB, int NQ>
 __device__ __forceinline__ void flash2_run(const AttnArgs& a, uint8_t* smem, const Flash2Ctx& cx, const Flash2Lane& ln, const bf16x8_t (&qh)[QT][2],
                                            int tile0, int64_t row0, int head, int r) {
-  constexpr int STAGE = 16384;                   // [64 keys][128 B] K image | the same for V
-  constexpr int NPW = (16 + WAVES - 1) / WAVES;  // a block is 16 1-KiB pieces (8 of K, 8 of V): wave w moves pieces w, w + WAVES, ...
+  constexpr int KEYS = KB * 16;                       // keys per block (KB 16-key tiles: 4 or 2)
+  constexpr int VOFF = KEYS * 128;                    // [KEYS][128 B] K image | the same for V
+  constexpr int STAGE = 2 * VOFF;
+  constexpr int NPC = STAGE / 1024;                   // a block is NPC 1-KiB pieces (half K, half V): wave w moves pieces w, w + WAVES, ...
+  constexpr int NPW = (NPC + WAVES - 1) / WAVES;
   const int T = cx.T;
-  const int my_pieces = (cx.wave + WAVES * (NPW - 1) < 16) ? NPW : NPW - 1;  // wave-uniform (12 waves: four waves move two, eight one)
+  const int my_pieces = (cx.wave + WAVES * (NPW - 1) < NPC) ? NPW : NPW - 1;  // wave-uniform (12 waves: four waves move two, eight one)
+  // source of piece i of a block: a wave-uniform block base (scalar registers) + a 32-bit lane offset that never changes -- the
+  // address arithmetic of a block is scalar (per-lane 64-bit row * stride products were 80 VALU cycles per piece: a fifth of
+  // the step).  Only the request for the LAST, partial block clamps its rows (a copy of the sequence's last row stands in for
+  // the rows past it: masked keys; finite V against P = 0) and pays a multiply.
+  uint32_t dma_off[NPW];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int piece = cx.wave + WAVES * i;
+    dma_off[i] = (uint32_t)(((piece < NPC / 2 ? piece : piece - NPC / 2) * 8 + cx.drow) * (int)cx.ld_bytes + (piece < NPC / 2 ? cx.k_src : cx.v_src));
+  }
   auto dma_block = [&](int kb, int slot) {
+    const uint8_t* base = cx.qkv8 + cx.row0_bytes + (int64_t)kb * (KEYS * cx.ld_bytes);  // wave-uniform
+    const bool partial = (kb + 1) * KEYS > T;                                            // wave-uniform
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
       const int piece = cx.wave + WAVES * i;
-      if (piece < 16) {  // wave-uniform
-        int key = kb * 64 + (piece & 7) * 8 + cx.drow;
-        key = key < T ? key : T - 1;  // rows past the sequence: a copy of its last row (masked keys; finite V against P = 0)
-        const uint8_t* src = cx.qkv8 + cx.row0_bytes + (int64_t)key * cx.ld_bytes + (piece < 8 ? cx.k_src : cx.v_src);
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(smem + slot * STAGE + piece * 1024), 16, 0, 0);
+      if (piece < NPC) {  // wave-uniform
+        uint32_t off = dma_off[i];
+        if (partial) {
+          int key = (piece < NPC / 2 ? piece : piece - NPC / 2) * 8 + cx.drow;
+          key = kb * KEYS + key < T ? key : T - 1 - kb * KEYS;
+          off = (uint32_t)(key * (int)cx.ld_bytes + (piece < NPC / 2 ? cx.k_src : cx.v_src));
+        }
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + off), (lds_void_t*)(smem + slot * STAGE + piece * 1024), 16, 0, 0);
       }
     }
   };
   float m[QT], l[QT];
-  f32x4_t oc[QT][4];
+  f32x4_t oc[QT][4], nm[QT];
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
-    m[t] = -INFINITY;
+    m[t] = TAPCLIP_FLASH2_PRESCALE ? 0.f : -INFINITY;
+    nm[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     l[t] = 0.f;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) oc[t][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
 
-  const int n_kb = (T + 63) >> 6, n_full = T >> 6;
+  const int n_kb = (T + KEYS - 1) / KEYS, n_full = T / KEYS;
 #pragma unroll
   for (int i = 0; i < NS - 1; ++i)
     if (i < n_kb) dma_block(i, i);
@@ -297,17 +360,17 @@ __device__ __forceinline__ void flash2_run(const AttnArgs& a, uint8_t* smem, con
   for (int kb = 0; kb < n_full; ++kb) {
     block_ready(kb);
     if (kb + NS - 1 < n_kb && !(TAPCLIP_FLASH2_ABL & 8)) dma_block(kb + NS - 1, slot == 0 ? NS - 1 : slot - 1);  // into the slot of block kb - 1
-    if constexpr (NQ > 0) flash2_step<QT, NQ, 4, false>(smem + slot * STAGE, smem + slot * STAGE + 8192, ln, qh, oc, m, l, kb * 64, T);
+    if constexpr (NQ > 0) flash2_step<QT, NQ, KB, false>(smem + slot * STAGE, smem + slot * STAGE + VOFF, ln, qh, oc, m, l, nm, kb * KEYS, T, kb == 0);
     slot = slot + 1 == NS ? 0 : slot + 1;
   }
   if (n_full < n_kb) {  // the last, partial block: 1 .. 63 keys (nothing left to request)
     block_ready(n_full);
     if constexpr (NQ > 0) {
       const uint8_t* Kb = smem + slot * STAGE;
-      const int rem = T - n_full * 64;
-      if (rem <= 16) flash2_step<QT, NQ, 1, true>(Kb, Kb + 8192, ln, qh, oc, m, l, n_full * 64, T);
-      else if (rem <= 32) flash2_step<QT, NQ, 2, true>(Kb, Kb + 8192, ln, qh, oc, m, l, n_full * 64, T);
-      else flash2_step<QT, NQ, 4, true>(Kb, Kb + 8192, ln, qh, oc, m, l, n_full * 64, T);
+      const int rem = T - n_full * KEYS;
+      if (rem <= 16) flash2_step<QT, NQ, 1, true>(Kb, Kb + VOFF, ln, qh, oc, m, l, nm, n_full * KEYS, T, n_full == 0);
+      else if (rem <= 32 || KB == 2) flash2_step<QT, NQ, 2, true>(Kb, Kb + VOFF, ln, qh, oc, m, l, nm, n_full * KEYS, T, n_full == 0);
+      else flash2_step<QT, NQ, (KB == 4 ? 4 : 2), true>(Kb, Kb + VOFF, ln, qh, oc, m, l, nm, n_full * KEYS, T, n_full == 0);
     }
   }
 #pragma unroll
@@ -328,7 +391,7 @@ __device__ __forceinline__ void flash2_run(const AttnArgs& a, uint8_t* smem, con
 
 // WAVES waves per workgroup, QT query tiles per wave (a chunk = WAVES * QT * 16 queries), WPS = waves per SIMD the build is
 // held to (register budget 512 / WPS)
-template <int WAVES, int QT, int NS, int WPS>
+template <int WAVES, int QT, int NS, int KB, int WPS>
 __global__ __launch_bounds__(WAVES * 64, WPS) void attn_flash2_kernel(AttnArgs a, int chunks) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -359,6 +422,19 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void attn_flash2_kernel(AttnArgs a
     for (int s = 0; s < 2; ++s) qh[t][s] = *reinterpret_cast<const bf16x8_t*>(a.qkv_hi + (row0 + qc) * ld + qcol + 32 * s + 8 * g);
   }
 
+  if constexpr (TAPCLIP_FLASH2_PRESCALE != 0) {
+    // q <- q * log2(e), rounded to the operand type again (one more rounding of q: 2^-9 / 2^-12 relative per element, of
+    // the size of the one it already carries)
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx) {
+        s16x8_t v = __builtin_bit_cast(s16x8_t, qh[t][sx]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (short)f2bf(bf2f((bf16_t)v[j]) * 1.44269504088896340736f);
+        qh[t][sx] = __builtin_bit_cast(bf16x8_t, v);
+      }
+  }
   // the Q fragments are consumed HERE as far as the compiler's wait-count pass can tell: left pending, their first use inside
   // the key loop gets an s_waitcnt vmcnt(0) that also drains the block DMAs issued behind them, in every iteration
 #pragma unroll
@@ -381,26 +457,26 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void attn_flash2_kernel(AttnArgs a
   const int kappa = 2 * (g & 1) + (qq >> 1);  // ((4 g + qq) >> 1) & 3
   ln.v_off0 = (4 * g + qq) * 128 + (((2 * pp) ^ kappa) << 4) + ((pp & 1) << 3);
 
-  if (nq == QT) flash2_run<WAVES, QT, NS, QT>(a, smem, cx, ln, qh, tile0, row0, head, r);
-  else if (QT > 1 && nq == 1) flash2_run<WAVES, QT, NS, 1>(a, smem, cx, ln, qh, tile0, row0, head, r);
-  else if (QT > 2 && nq == 2) flash2_run<WAVES, QT, NS, (QT > 2 ? 2 : 0)>(a, smem, cx, ln, qh, tile0, row0, head, r);
-  else if (QT > 3 && nq == 3) flash2_run<WAVES, QT, NS, (QT > 3 ? 3 : 0)>(a, smem, cx, ln, qh, tile0, row0, head, r);
-  else flash2_run<WAVES, QT, NS, 0>(a, smem, cx, ln, qh, tile0, row0, head, r);
+  if (nq == QT) flash2_run<WAVES, QT, NS, KB, QT>(a, smem, cx, ln, qh, tile0, row0, head, r);
+  else if (QT > 1 && nq == 1) flash2_run<WAVES, QT, NS, KB, 1>(a, smem, cx, ln, qh, tile0, row0, head, r);
+  else if (QT > 2 && nq == 2) flash2_run<WAVES, QT, NS, KB, (QT > 2 ? 2 : 0)>(a, smem, cx, ln, qh, tile0, row0, head, r);
+  else if (QT > 3 && nq == 3) flash2_run<WAVES, QT, NS, KB, (QT > 3 ? 3 : 0)>(a, smem, cx, ln, qh, tile0, row0, head, r);
+  else flash2_run<WAVES, QT, NS, KB, 0>(a, smem, cx, ln, qh, tile0, row0, head, r);
 }
 
-template <int WAVES, int QT, int NS, int WPS>
+template <int WAVES, int QT, int NS, int KB, int WPS>
 hipError_t launch_flash2_cfg(const AttnArgs& a, hipStream_t s) {
-  constexpr int smem_bytes = NS * 16384;
+  constexpr int smem_bytes = NS * KB * 4096;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash2_kernel<WAVES, QT, NS, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash2_kernel<WAVES, QT, NS, KB, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   const int n_qt = (a.T + 15) / 16;
   const int chunks = (n_qt + WAVES * QT - 1) / (WAVES * QT);
   const int pairs8 = (a.n_seq * a.H + 7) / 8;
-  hipLaunchKernelGGL((attn_flash2_kernel<WAVES, QT, NS, WPS>), dim3((unsigned)(pairs8 * 8 * chunks)), dim3(WAVES * 64), smem_bytes, s, a, chunks);
+  hipLaunchKernelGGL((attn_flash2_kernel<WAVES, QT, NS, KB, WPS>), dim3((unsigned)(pairs8 * 8 * chunks)), dim3(WAVES * 64), smem_bytes, s, a, chunks);
   return hipGetLastError();
 }
 
@@ -418,12 +494,12 @@ void flash2_set_cfg(int cfg) { g_flash2_cfg = cfg; }  // tools/attn_bench: switc
 
 hipError_t launch_flash2(const AttnArgs& a, hipStream_t s) {
   switch (flash2_cfg()) {
-    case 42: return launch_flash2_cfg<4, 2, 3, 3>(a, s);
-    case 83: return launch_flash2_cfg<8, 3, 3, 2>(a, s);
-    case 122: return launch_flash2_cfg<12, 2, 6, 3>(a, s);
-    case 123: return launch_flash2_cfg<12, 2, 4, 3>(a, s);
-    case 62: return launch_flash2_cfg<6, 2, 4, 3>(a, s);
-    default: return launch_flash2_cfg<12, 2, 6, 3>(a, s);
+    // (measured at ViT-L/14@336, batch 128, same box, interleaved, every element of every output compared with the first
+    //  kernel's: profiles/r05_attn_bench_*.log)
+    case 122: return launch_flash2_cfg<12, 2, 6, 4, 3>(a, s);  // one 12-wave workgroup per CU, 2 chunks of 384 queries: 365-390 us
+    case 822: return launch_flash2_cfg<8, 2, 6, 2, 4>(a, s);   // 8 waves, 32-key blocks (16 fewer score registers: 128 VGPRs), 3 chunks: 315 us
+    case 424: return launch_flash2_cfg<4, 2, 4, 2, 4>(a, s);   // 4 waves, 32-key blocks, four workgroups per CU: 270 us
+    default: return launch_flash2_cfg<4, 2, 3, 4, 3>(a, s);    // 4 waves x 2 tiles (128 queries), 64-key blocks, three workgroups per CU: 258 us
   }
 }
 

@@ -224,6 +224,39 @@ def test_long_sequence_flash_attention(eng, precision, causal):
         tower.forward(x.to(DEV), want_mean=True)  # write-back is only built for <= 256 tokens
 
 
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+@pytest.mark.parametrize("size", [224, 280, 336, 448])
+def test_long_sequence_attention_token_counts(eng, precision, size):
+    """The LDS-DMA attention kernel of T > 256 (csrc/attention_long.hip) at token counts that put the ragged ends everywhere:
+    patch 14 at 224 / 280 / 336 / 448 pixels = 257 / 401 / 577 / 1 025 tokens (last key block of 1, 17, 1 and 1 keys; last
+    query chunk of 1, 10, 5 and 1 query tiles), one block at d = 256 / 4 heads, against the fp32 oracle; twice for bits."""
+    d, heads, mlp = 256, 4, 512
+    cfg = configs.ClipDims(f"long{size}", 64, size, 14, configs.TowerDims(d, 1, heads, mlp), configs.TowerDims(128, 1, 2, 256), vocab=16, ctx=8)
+    ocfg = clip_ref.ClipDims(f"long{size}", 64, size, 14, clip_ref.TowerDims(d, 1, heads, mlp), clip_ref.TowerDims(128, 1, 2, 256), vocab=16, ctx=8)
+    tokens = (size // 14) ** 2 + 1
+    sd = {}
+    synth._tower(sd, "visual.transformer.", d, 1, mlp, seed=21)
+    g = torch.Generator().manual_seed(size)
+    sd["visual.conv1.weight"] = torch.randn(d, 3, 14, 14, generator=g) * 0.03
+    sd["visual.class_embedding"] = torch.randn(d, generator=g) * 0.3
+    sd["visual.positional_embedding"] = torch.randn(tokens, d, generator=g) * 0.3
+    for k in ("ln_pre", "ln_post"):
+        sd[f"visual.{k}.weight"] = 1.0 + 0.1 * torch.randn(d, generator=g)
+        sd[f"visual.{k}.bias"] = 0.05 * torch.randn(d, generator=g)
+    sd["visual.proj"] = torch.randn(d, 64, generator=g) * d ** -0.5
+    # (every row of the one block: with the CLS-only last block the long kernel would not run at all)
+    tower = eng.VisionTower(cfg, sd, DEV, precision, prune_last_block=False)
+    images = synth.make_images(3, cfg, 31)
+    a = tower.encode_image(images.to(DEV)).cpu()
+    b = tower.encode_image(images.to(DEV)).cpu()
+    with torch.no_grad():
+        ref = clip_ref.encode_image(images, sd, ocfg)
+    _report(f"long attention {tokens} tokens {precision}", a, ref)
+    assert torch.equal(a, b), "same input twice must be bit-identical"
+    assert bool(torch.isfinite(a).all())
+    assert rel_max(a, ref) < (TOL if precision == "fp16" else TOL_BF16)
+
+
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 def test_encode_image_vit_l14_336_geometry(eng, precision):
     """BASELINE configs[4] geometry (patch 14 -> K = 588 padded to 640, 577 tokens, width 1024, 16 heads,
