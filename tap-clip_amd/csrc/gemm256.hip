@@ -651,6 +651,36 @@ __global__ __launch_bounds__(256) void splitk_fixup_kernel(GemmArgs g, int n_til
 
 constexpr int SPLIT_WS_TILES = 256;  // at most one partial tile per workgroup
 
+// CUs a launch is sized for (one persistent workgroup each; a multiple of 8 so every XCD gets the same number)
+static int device_cus() {
+  static int n_cu_dev = 0;
+  if (n_cu_dev == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    n_cu_dev = prop.multiProcessorCount / 8 * 8;
+    if (n_cu_dev < 8) n_cu_dev = 8;
+  }
+  return n_cu_dev;
+}
+
+// K-split of the last, partial round (launch_t below): into how many parts its `rem` tiles are cut, 0 = whole tiles
+static int tail_split_parts(int epi, bool split, int bn, int64_t tiles, int n_cu, int32_t K, bool have_ws) {
+  static const bool no_tail_split = getenv("TAPCLIP_NO_TAIL_SPLIT") != nullptr;
+  if (!(epi == EPI_BIAS_BF16 || epi == EPI_BIAS_GELU_BF16 || epi == EPI_BIAS_F32) || !have_ws || no_tail_split) return 0;
+  const int64_t full = tiles / n_cu, rem = tiles - full * n_cu;
+  const int ks = (split ? 3 : 1) * (K / BKS);
+  if (!(rem > 0 && rem * 2 <= n_cu && (full == 0 || (bn == 256 && !split)))) return 0;
+  int parts = (int)(n_cu / rem);
+  // a part shorter than ~16 K steps is all pipeline fill and drain: it costs more than the idle CUs
+  static const int min_ks = [] {
+    const char* e = getenv("TAPCLIP_TAIL_MIN_KS");
+    return e ? atoi(e) : 16;
+  }();
+  while (parts > 1 && (ks % parts != 0 || ks / parts < (min_ks > 4 ? min_ks : 4))) --parts;
+  return (parts >= 2 && rem * parts <= SPLIT_WS_TILES) ? parts : 0;
+}
+
 template <int EPI, bool SPLIT, int BN>
 hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
   constexpr int NS = 4;
@@ -663,15 +693,9 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const int64_t tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
-  // persistent: one workgroup per CU (a multiple of 8 so every XCD gets the same number)
-  static int n_cu_dev = 0;
-  if (n_cu_dev == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-    n_cu_dev = prop.multiProcessorCount / 8 * 8;
-    if (n_cu_dev < 8) n_cu_dev = 8;
-  }
+  // persistent: one workgroup per CU
+  const int n_cu_dev = device_cus();
+  if (n_cu_dev == 0) return hipErrorUnknown;
   const int n_cu = (a.n_cu >= 8 && a.n_cu < n_cu_dev) ? a.n_cu / 8 * 8 : n_cu_dev;  // (a CU-masked stream: one workgroup per CU of the mask)
   int64_t nwg = tiles < n_cu ? (tiles + 7) / 8 * 8 : n_cu;
   GemmArgs b = a;
@@ -684,7 +708,6 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
   // The whole rounds run as whole tiles; each of the remaining R tiles is computed by S = floor(256 / R)
   // workgroups over 1/S of K into fp32 partial tiles, summed by splitk_fixup_kernel.
   b.split_parts = 0;
-  static const bool no_tail_split = getenv("TAPCLIP_NO_TAIL_SPLIT") != nullptr;
   // The same machinery covers a GEMM with fewer tiles than half the CUs (the text tower's c_proj: 96 tiles of
   // K = 2048 on 256 CUs, 40 us): every tile is K-split (split_from = 0) and the grid grows to tiles x parts.
   // (EPI_BIAS_F32: the K = 1536 / 2048, N = 512 dX GEMMs of the text tower's backward -- one partial round of 48 - 96 tiles
@@ -692,22 +715,13 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
   // (split-bf16, round 3: only the second case -- EVERY tile of the launch split alike, so a row's bits depend on the
   // launch's M and never on which rows share it; its three products are one K sequence of 3 K / 32 steps, cut anywhere.
   // The text tower of the fp16 default mode at 65 classes: c_proj 192 dependent steps on 96 of 256 CUs.)
-  if ((EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_BIAS_F32) && a.split_ws != nullptr && !no_tail_split) {
-    const int64_t full = tiles / n_cu, rem = tiles - full * n_cu;
-    const int ks = (SPLIT ? 3 : 1) * (a.K / BKS);
-    if (rem > 0 && rem * 2 <= n_cu && (full == 0 || (BN == 256 && !SPLIT))) {
-      int parts = (int)(n_cu / rem);
-      // a part shorter than ~16 K steps is all pipeline fill and drain: it costs more than the idle CUs
-      static const int min_ks = [] {
-        const char* e = getenv("TAPCLIP_TAIL_MIN_KS");
-        return e ? atoi(e) : 16;
-      }();
-      while (parts > 1 && (ks % parts != 0 || ks / parts < (min_ks > NS ? min_ks : NS))) --parts;
-      if (parts >= 2 && rem * parts <= SPLIT_WS_TILES) {
-        b.split_from = (int)(full * n_cu);
-        b.split_parts = parts;
-        if (full == 0) nwg = (rem * parts + 7) / 8 * 8;
-      }
+  {
+    const int parts = tail_split_parts(EPI, SPLIT, BN, tiles, n_cu, a.K, a.split_ws != nullptr);
+    if (parts >= 2) {
+      const int64_t full = tiles / n_cu, rem = tiles - full * n_cu;
+      b.split_from = (int)(full * n_cu);
+      b.split_parts = parts;
+      if (full == 0) nwg = (rem * parts + 7) / 8 * 8;
     }
   }
   hipLaunchKernelGGL((gemm256_kernel<EPI, SPLIT, BN, NS>), dim3((unsigned)nwg), dim3(512), smem_bytes, s, b);
@@ -727,12 +741,23 @@ hipError_t launch_e(const GemmArgs& a, bool split, hipStream_t s) {
     const char* e = getenv("TAPCLIP_GEMM_BN");  // tests: pin the n-tile width
     return e ? atoi(e) : 0;
   }();
-  // 256-wide tiles have 1.5x the FLOP per staged byte (the main loop is L2->LDS bound) but half as many
-  // tiles: take them unless their last, partial round of 256 workgroups wastes more than that gains
+  // 256-wide tiles have 1.5x the FLOP per staged byte (the main loop is L2->LDS bound) but half as many tiles: take them
+  // unless their last, partial round wastes more than that gains.  Round 5: the estimate knows the K-split of that round
+  // (a split tail costs ~0.55 of a round, not a whole one) and prices a 128-wide round at 0.7 of a 256-wide one (measured
+  // 0.65 at K = 768, 0.76 at K = 3072; it assumed 0.625).  Measured at the row counts of small batches (tools/gemm_sweep.sh,
+  // profiles/r05_gemm_small_batch_sweep.log): c_proj at 25 216 rows (batch 128) 175 -> 116 us, out_proj 55 -> 45, c_fc /
+  // c_proj at 6 304 rows (batch 32) 54 -> 50 / 57 -> 48; every choice at 50 432 rows (batch 256) is the one made before.
   bool wide = false;
   if (a.N % 256 == 0) {
-    const double r256 = (double)(tiles_m * (a.N / 256)) / 256.0, r128 = (double)(tiles_m * (a.N / 128)) / 256.0;
-    const double t256 = std::ceil(r256) * 1.0, t128 = std::ceil(r128) * 0.5 * 1.25;  // relative time per round
+    const int n_cu = (a.n_cu >= 8 && a.n_cu < device_cus()) ? a.n_cu / 8 * 8 : device_cus();
+    auto rounds = [&](int bn, double per_round) {
+      const int64_t tiles = tiles_m * (a.N / bn);
+      const int64_t full = tiles / n_cu, rem = tiles - full * n_cu;
+      if (rem == 0) return (double)full * per_round;
+      const bool cut = tail_split_parts(EPI, split, bn, tiles, n_cu, a.K, a.split_ws != nullptr) >= 2;
+      return ((double)full + (cut ? 0.55 : 1.0)) * per_round;
+    };
+    const double t256 = n_cu > 0 ? rounds(256, 1.0) : 0.0, t128 = n_cu > 0 ? rounds(128, 0.7) : 1.0;
     wide = forced_bn == 256 || (forced_bn != 128 && t256 <= t128);
   }
   // (the GELU-backward epilogue used to be pinned to 128-wide tiles: at 256 it spilled 84 B/lane -- its exp + erf polynomial

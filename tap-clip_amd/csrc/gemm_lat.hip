@@ -241,7 +241,11 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
 
 template <int EPI, bool SPLIT>
 hipError_t launch_e(const GemmArgs& a, hipStream_t s) {
-  // the tile with the least (rounds of 256 workgroups) x (operand bytes per workgroup); ties go to the larger tile
+  // the tile with the least (rounds of 256 workgroups) x (time of one tile); near-ties go to the larger tile.  Round 5: the
+  // time of a tile is a measured line in K -- 5.8 + 0.0120 K us (128 x 128), 3.1 + 0.0096 K (128 x 64), 1.6 + 0.0044 K (64 x 64)
+  // at one 16-bit product (tools/gemm_sweep.sh at 1 576 rows, profiles/r05_gemm_small_batch_sweep.log) -- where rounds x
+  // (operand bytes + a constant) chose 128 x 128 for the two rounds of c_fc at batch 8 (30 us; 64 x 64: five rounds, 26 us).
+  // The three split-bf16 products scale every term alike: the same choice.
   static const int forced = [] {
     const char* e = getenv("TAPCLIP_GEMM_LAT_TILE");  // experiments: 0 = 128x128, 1 = 128x64, 2 = 64x64
     return e ? atoi(e) : -1;
@@ -252,8 +256,9 @@ hipError_t launch_e(const GemmArgs& a, hipStream_t s) {
   for (int c = 0; c < 3; ++c) {
     if (a.N % bn[c] != 0) continue;
     const int64_t tiles = ((a.M + bm[c] - 1) / bm[c]) * (a.N / bn[c]);
-    const double cost = (double)((tiles + 255) / 256) * ((double)(bm[c] + bn[c]) * a.K + 40000.0);  // (+ a fixed cost per round)
-    if (best < 0 || cost < best_cost) best = c, best_cost = cost;
+    const double fix[3] = {5.8, 3.1, 1.6}, per_k[3] = {0.0120, 0.0096, 0.0044};
+    const double cost = (double)((tiles + 255) / 256) * (fix[c] + per_k[c] * a.K);
+    if (best < 0 || cost < 0.95 * best_cost) best = c, best_cost = cost;
   }
   if (forced >= 0 && forced < 3 && a.N % bn[forced] == 0) best = forced;
   switch (best) {
