@@ -498,7 +498,7 @@ hipError_t launch_flash2(const AttnArgs& a, hipStream_t s) {
     //  kernel's: profiles/r05_attn_bench_*.log)
     case 122: return launch_flash2_cfg<12, 2, 6, 4, 3>(a, s);  // one 12-wave workgroup per CU, 2 chunks of 384 queries: 365-390 us
     case 822: return launch_flash2_cfg<8, 2, 6, 2, 4>(a, s);   // 8 waves, 32-key blocks (16 fewer score registers: 128 VGPRs), 3 chunks: 315 us
-    case 424: return launch_flash2_cfg<4, 2, 4, 2, 4>(a, s);   // 4 waves, 32-key blocks, four workgroups per CU: 270 us
+    // (4 waves, 32-key blocks, four workgroups per CU -- <4, 2, 4, 2, 4> -- : 270 us with 5 spilled dwords; not kept)
     default: return launch_flash2_cfg<4, 2, 3, 4, 3>(a, s);    // 4 waves x 2 tiles (128 queries), 64-key blocks, three workgroups per CU: 258 us
   }
 }

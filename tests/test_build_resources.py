@@ -23,6 +23,8 @@ HOT = [
     ("gemm256.hip", r"gemm256_kernelILi[0-4]ELb0ELi(256|128)ELi4E|gemm256_kernelILi5ELb0ELi128ELi4E"),
     ("gemm_mx8.hip", r"gemm_mx8_kernelILi[046]E"),
     ("attention.hip", r"attn_kernelILi(6|14)ELb0E|attn_flash_kernelILi(4|8)ELi[23]ELb0E"),
+    # every geometry of the LDS-DMA kernel: a spill would put scratch traffic into its hand-counted vmcnt queue
+    ("attention_long.hip", r"attn_flash2_kernelILi"),
 ]
 # the 13-key-tile attention kernel is compiled for 6 waves per SIMD (three workgroups per CU) and parks 3 dwords
 SMALL_SPILL = {"attention.hip": (r"attn_kernelILi13ELb0E", 16)}
@@ -47,7 +49,7 @@ def _usage(src):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
 def test_hot_kernels_use_no_scratch():
-    with ThreadPoolExecutor(max_workers=3) as ex:
+    with ThreadPoolExecutor(max_workers=4) as ex:
         results = list(ex.map(_usage, [s for s, _ in HOT]))
     for (src, pat), usage in zip(HOT, results):
         hot = {k: v for k, v in usage.items() if re.search(pat, k)}
