@@ -372,11 +372,96 @@ def g_eval_metrics(ref):
     print(f"  accuracy {acc:.2f}  per-class {per}  min top-2 margin {margin:.3e}")
 
 
+def g_fullmodel_b16_b32c5(ref):
+    """The reference scripts' OWN operating point (train.py:29-39,75-81; test_cross_domain.py:30): batch 32, 5 classes, 5
+    context tokens (T = 82) -- on ViT-B/16 (BASELINE's model; the scripts name no architecture beyond a checkpoint path).
+    The literal loop: 5 x (32 + 1) text passes and one 32-image pass of the image tower, with the training loop's gradients."""
+    cfg = clip_ref.CONFIGS["ViT-B-16"]
+    sd = synth.make_state_dict(cfg, seed=2)
+    names = class_list(5)
+    P, B = 5, 32
+    table = token_table(names, cfg)
+    images = synth.make_images(B, cfg, 0)
+    labels = synth.make_labels(B, len(names))
+    for semantics in ("literal", "intended"):
+        t0 = time.time()
+        clip = ref_harness.RefClip(cfg, sd, semantics, ref_harness.FixedTokenizer(table))
+        torch.manual_seed(1234)
+        model = ref["FullModel"](names, clip, prompt_len=P, adjustor_method="scale", class_specific=True)
+        _seed_context(model, names, cfg, P, seed=1)
+        out = model(images, labels)
+        out["loss"].backward()
+        grads = torch.stack([model.prompt_learner.context_bank[c].grad for c in names], 0)
+        arrays = dict(logits=out["logits"], loss=out["loss"], labels=labels,
+                      token_ids=torch.cat([table[f"a photo of a {c}"] for c in names], 0),
+                      context_grad=grads, logit_scale_grad=model.logit_scale.grad)
+        if semantics == "intended":
+            clip.reset()
+            with torch.no_grad():
+                clip.model.transformer(model.prompt_learner().detach())
+            amap = clip.get_attention_map()  # [5, 82, 82]
+            arrays["attn_map"] = amap
+            arrays["attribution"] = model.attribution_monitor(amap)
+        _save(f"fullmodel_{semantics}_vitb16_b32_c5", seed_weights=2, seed_images=0, seed_context=1, batch=B, prompt_len=P,
+              class_names=np.array(names), **arrays)
+        print(f"  {semantics}: {time.time() - t0:.0f}s")
+
+
+def g_stress_vitb16(ref):
+    """Hostile statistics at ViT-B/16 dims (synth.make_stress_state_dict / make_stress_images): LayerNorm gains with x10-x30
+    channels, residual-stream outliers of |x| = 100-300, near one-hot last-block softmax rows, saturated patches -- what the
+    IEEE-half default mode must hold 1e-3 on.  Goldens from THREE sources: the fp32 oracle, HF `transformers` CLIP carrying the
+    same weights (independent code), and the reference's own FullModel (8 classes, 16 context tokens, batch 4, literal loop)."""
+    from oracle import hf_harness
+
+    cfg = clip_ref.CONFIGS["ViT-B-16"]
+    sd = synth.make_stress_state_dict(cfg, seed=7)
+    names = class_list(8)
+    P, B, KEEP = 16, 4, 3
+    table = token_table(names, cfg)
+    images = synth.make_stress_images(B, cfg, 0)
+    labels = synth.make_labels(B, len(names))
+    t0 = time.time()
+    with torch.no_grad():
+        emb = clip_ref.encode_image(images, sd, cfg)
+    hf = hf_harness.build_hf_clip(cfg, sd)
+    emb_hf = hf_harness.image_features(hf, images)
+    print(f"  image tower: oracle vs HF rel-max {float((emb - emb_hf).abs().max() / emb_hf.abs().max()):.3e}  ({time.time() - t0:.0f}s)")
+    tokens = torch.cat([table[f"a photo of a {c}"] for c in names], 0)
+    ctx = synth.make_prompts(len(names), P, cfg, seed=1)[0]
+    prompts = torch.cat([ctx, sd["token_embedding.weight"][tokens]], dim=1)  # [8, 93, 512]
+    with torch.no_grad():
+        hidden_hf, probs_hf = hf_harness.raw_text_transformer(hf, prompts)
+    arrays = dict(image_embeddings=emb, image_embeddings_hf=emb_hf, token_ids=tokens,
+                  raw_hidden_last_hf=hidden_hf[:, -1], raw_hidden_hf=hidden_hf[:KEEP], raw_attn_mean_hf=probs_hf[:KEEP].mean(1),
+                  raw_attn_max_prob_hf=probs_hf.max())
+    for semantics in ("intended",):
+        clip = ref_harness.RefClip(cfg, sd, semantics, ref_harness.FixedTokenizer(table))
+        torch.manual_seed(1234)
+        model = ref["FullModel"](names, clip, prompt_len=P, adjustor_method="scale", class_specific=True)
+        _seed_context(model, names, cfg, P, seed=1)
+        # the images as the stressed batch: RefClip.encode_image is the fp32 oracle
+        out = model(images, labels)
+        out["loss"].backward()
+        grads = torch.stack([model.prompt_learner.context_bank[c].grad for c in names], 0)
+        clip.reset()
+        with torch.no_grad():
+            hid = clip.model.transformer(model.prompt_learner().detach())
+        amap = clip.get_attention_map()
+        arrays.update(logits=out["logits"], loss=out["loss"], labels=labels, context_grad=grads, logit_scale_grad=model.logit_scale.grad,
+                      attn_map=amap[:KEEP], attn_map_last_col=amap[:, :, -1], attribution=model.attribution_monitor(amap),
+                      raw_hidden_last=hid[:, -1])
+    print(f"  text side: max probability of the last block {float(probs_hf.max()):.4f}; oracle vs HF hidden(last) rel-max "
+          f"{float((arrays['raw_hidden_last'] - hidden_hf[:, -1]).abs().max() / hidden_hf[:, -1].abs().max()):.3e}")
+    _save("stress_vitb16", seed_weights=7, seed_images=0, seed_context=1, batch=B, prompt_len=P, class_names=np.array(names), **arrays)
+    print(f"  {time.time() - t0:.0f}s")
+
+
 ALL = {"attribution_monitor": g_attribution_monitor, "prompt_adjustor": g_prompt_adjustor,
        "fullmodel_tiny": g_fullmodel_tiny, "block_real_dims": g_block_real_dims, "image_tower": g_image_tower,
        "fullmodel_b32": g_fullmodel_b32, "fullmodel_b16_c65": g_fullmodel_b16_c65, "image_tower_l14": g_image_tower_l14,
        "fullmodel_l14": g_fullmodel_l14, "checkpoint": g_checkpoint, "eval_metrics": g_eval_metrics,
-       "hf_clip_vitb16": g_hf_clip_vitb16}
+       "hf_clip_vitb16": g_hf_clip_vitb16, "fullmodel_b16_b32c5": g_fullmodel_b16_b32c5, "stress_vitb16": g_stress_vitb16}
 
 
 def main():

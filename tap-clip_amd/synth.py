@@ -136,6 +136,69 @@ def make_state_dict_device(cfg: ClipDims, seed: int = 2, device="cuda", vision: 
     return out
 
 
+def make_stress_state_dict(cfg: ClipDims, seed: int = 7) -> Dict[str, torch.Tensor]:
+    """The seeded state dict of `make_state_dict` bent towards what TRAINED CLIP weights look like and N(0, d^-1/2) draws do
+    not (the 1e-3 claim of the IEEE-half mode had met one benign distribution only):
+      * LayerNorm gains log-normal (sigma 0.5) with six channels per norm at x10 .. x30;
+      * six residual-stream channels per tower driven to |x| = 100 .. 300 by the c_proj bias of block 1 (the "massive
+        activations" of trained ViTs: every later LayerNorm is dominated by them);
+      * the q and k rows of the LAST block's in_proj scaled so that its scores spread over +-30 (near one-hot softmax rows);
+      * c_fc rows of two blocks scaled x4 (pre-activations far into both GELU tails);
+      * the read-outs (ln_post gain, text_projection rows) all but ignore the six outlier channels, as trained ones do.
+    Same keys and shapes; a pure function of (cfg, seed)."""
+    sd = make_state_dict(cfg, seed)
+    outliers = {}
+    for prefix, dims in (("visual.transformer.", cfg.vision), ("transformer.", cfg.text)):
+        w, L = dims.width, dims.layers
+        for i in range(L):
+            for ln in ("ln_1", "ln_2"):
+                k = f"{prefix}resblocks.{i}.{ln}.weight"
+                g = torch.exp(normal([w], seed, k + ".stress", 0.5))
+                hot = integers([6], seed, k + ".hot", w)
+                g[hot] = g[hot] * (10.0 + 20.0 * (integers([6], seed, k + ".hotx", 1000).float() / 999.0))
+                sd[k] = g
+        hot = integers([6], seed, prefix + "outlier.channels", w)
+        mag = 100.0 + 200.0 * (integers([6], seed, prefix + "outlier.mag", 1000).float() / 999.0)
+        sign = torch.where(integers([6], seed, prefix + "outlier.sign", 2) == 0, -1.0, 1.0)
+        b = sd[f"{prefix}resblocks.1.mlp.c_proj.bias"].clone()
+        b[hot] = mag * sign
+        sd[f"{prefix}resblocks.1.mlp.c_proj.bias"] = b
+        k = f"{prefix}resblocks.{L - 1}.attn.in_proj_weight"
+        wq = sd[k].clone()
+        wq[: 2 * w] *= 3.2  # q and k rows: scores x 10
+        sd[k] = wq
+        for i in (2, L - 2):
+            k = f"{prefix}resblocks.{i}.mlp.c_fc.weight"
+            sd[k] = sd[k] * 4.0
+        outliers[prefix] = hot
+    for k in ("visual.ln_pre.weight", "visual.ln_post.weight", "ln_final.weight"):
+        w = sd[k].numel()
+        g = torch.exp(normal([w], seed, k + ".stress", 0.5))
+        hot = integers([6], seed, k + ".hot", w)
+        g[hot] = g[hot] * 15.0
+        sd[k] = g
+    # what training does with such channels: the read-outs ignore them (left at full weight, the six constants of +-300 ARE the
+    # embedding and every image / class looks alike: a stress case that tests nothing).  The towers' internals keep them.
+    sd["visual.ln_post.weight"][outliers["visual.transformer."]] = 0.01
+    sd["visual.ln_post.bias"][outliers["visual.transformer."]] = 0.0
+    sd["text_projection"][outliers["transformer."]] *= 0.01
+    return sd
+
+
+def make_stress_images(batch: int, cfg: ClipDims, seed: int = 0) -> torch.Tensor:
+    """[B,3,S,S]: N(0,1) pixels with a third of the patches SATURATED -- whole 16 x 16 (patch-sized) squares at the CLIP-normalised
+    value of pure white (+1.93 / +2.07 / +2.15 per channel) or pure black (-1.79 / -1.75 / -1.48)."""
+    x = normal([batch, 3, cfg.image_size, cfg.image_size], seed, "images.stress")
+    g = cfg.image_size // cfg.patch
+    pick = integers([batch, g, g], seed, "images.stress.pick", 6)  # 0: white, 1: black, else untouched
+    white = torch.tensor([1.93, 2.07, 2.15]).view(1, 3, 1, 1)
+    black = torch.tensor([-1.79, -1.75, -1.48]).view(1, 3, 1, 1)
+    m = pick.repeat_interleave(cfg.patch, 1).repeat_interleave(cfg.patch, 2).unsqueeze(1)
+    s_ = g * cfg.patch
+    x[:, :, :s_, :s_] = torch.where(m == 0, white, torch.where(m == 1, black, x[:, :, :s_, :s_]))
+    return x
+
+
 def make_images(batch: int, cfg: ClipDims, seed: int = 0) -> torch.Tensor:
     """[B,3,S,S] fp32 ~ N(0,1): stands in for CLIP-normalised pixels."""
     return normal([batch, 3, cfg.image_size, cfg.image_size], seed, "images")

@@ -81,6 +81,40 @@ def test_fullmodel_vitb16_65_classes_vs_reference(semantics):
         torch.cuda.empty_cache()
 
 
+# ---- the reference scripts' own operating point ----------------------------------------------------------------
+@pytest.mark.parametrize("semantics", ["literal", "intended"])
+def test_fullmodel_vitb16_batch_32_five_classes_vs_reference(semantics):
+    """What the reference's train.py / test_cross_domain.py really run (train.py:29-39,75-81): batch 32, 5 classes, 5 context
+    tokens (T = 82) -- on ViT-B/16 -- against the reference FullModel's own logits, loss, gradients, map and attribution.
+    At 6 304 image rows the tower is in another regime than at BASELINE's batch 256 (1.2 rounds of GEMM tiles, every c_proj tile
+    K-split): this is the shape a user who drops the library into those scripts gets."""
+    g = golden(f"fullmodel_{semantics}_vitb16_b32_c5")
+    ref = torch.from_numpy(g["logits"])
+    labels = torch.from_numpy(g["labels"]).to(DEV)
+    names = g["class_names"].tolist()
+    for precision, tol in (("bf16x3", TOL), ("fp16", TOL)):
+        model, images = _build_full("ViT-B-16", g, semantics, precision)
+        assert images.shape[0] == 32
+        model.train()
+        out = model(images, labels)
+        out["loss"].backward()
+        _report(f"FullModel ViT-B/16 batch 32, 5 classes, P=5 {semantics} {precision} logits", out["logits"].detach(), ref)
+        assert out["logits"].shape == (32, 5)
+        assert rel_max(out["logits"].detach().cpu(), ref) < tol
+        assert abs(float(out["loss"]) - float(g["loss"])) < tol * max(1.0, abs(float(g["loss"])))
+        grad = torch.stack([model.prompt_learner.context_bank[c].grad for c in names], 0).cpu()
+        _report(f"  context grad {precision}", grad, torch.from_numpy(g["context_grad"]))
+        assert rel_max(grad, torch.from_numpy(g["context_grad"])) < tol
+        assert abs(float(model.logit_scale.grad) - float(g["logit_scale_grad"])) < tol * max(1.0, abs(float(g["logit_scale_grad"])))
+        if semantics == "intended":
+            amap = model.clip.attention_maps[0].cpu()
+            assert amap.shape == (5, 82, 82)
+            assert rel_max(amap, torch.from_numpy(g["attn_map"])) < tol
+            assert rel_max(model.last_attribution.cpu(), torch.from_numpy(g["attribution"])) < tol
+        del model
+        torch.cuda.empty_cache()
+
+
 def test_per_head_write_back_vitb16_65_classes(eng):
     """The per-head probabilities [n, 8, 93, 93] that a hook on resblocks[-1].attn receives (reference
     clip_wrapper.py:29-40, intended semantics) against the reference run's own rows."""

@@ -350,3 +350,21 @@ def test_host_tail_run():
     tok[2, 8] += 1.0
     assert host_tail_run(tok) == 1
     assert host_tail_run(torch.ones(2, 5, 3)) == 5
+
+
+def test_stress_golden_oracle_against_the_independent_implementation():
+    """tests/golden/stress_vitb16.npz (hostile statistics, tests/test_gpu_stress.py): the fp32 oracle of THIS checkout reproduces
+    its committed embeddings, and those agree with HF `transformers` CLIP carrying the same weights -- on outlier channels of
+    |x| = 300 and near one-hot softmax rows too, the restatement and the independent code are one function."""
+    g = golden("stress_vitb16")
+    cfg = clip_ref.CONFIGS["ViT-B-16"]
+    sd = synth.make_stress_state_dict(cfg, seed=int(g["seed_weights"]))
+    images = synth.make_stress_images(2, cfg, int(g["seed_images"]))
+    with torch.no_grad():
+        emb = clip_ref.encode_image(images, sd, cfg)
+    assert rel_max(emb, torch.from_numpy(g["image_embeddings"][:2])) < 1e-5
+    assert rel_max(torch.from_numpy(g["image_embeddings"]), torch.from_numpy(g["image_embeddings_hf"])) < 1e-5
+    assert rel_max(torch.from_numpy(g["raw_hidden_last"]), torch.from_numpy(g["raw_hidden_last_hf"])) < 1e-5
+    assert float(g["raw_attn_max_prob_hf"]) > 0.9  # near one-hot rows are really there
+    # the statistics the case is built for: a LayerNorm gain beyond x10, an outlier bias beyond 100
+    assert float(sd["visual.transformer.resblocks.5.ln_1.weight"].max()) > 10 and float(sd["visual.transformer.resblocks.1.mlp.c_proj.bias"].abs().max()) >= 100
