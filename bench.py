@@ -483,6 +483,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if world > 1:
+        # The FIRST collective under a deadline: a rank whose peer never arrives (a dead process, a GPU that is not there, an
+        # RCCL bootstrap that hangs) must exit non-zero naming itself, not sit in a stream wait until the driver kills the
+        # whole run.  The step is enqueued, an event behind it polled; past the deadline this process reports its rank and
+        # device on stderr and ends itself (os._exit: no clean-up that could block on the same collective; the launcher then
+        # tears the other ranks down).  torch's own watchdog covers asynchronous RCCL errors of its process group
+        # (TORCH_NCCL_ASYNC_ERROR_HANDLING); the C-ABI exchange step has tapclip_comm_check for the same purpose.
+        deadline = float(os.environ.get("TAPCLIP_FIRST_COLLECTIVE_TIMEOUT", "180"))
+        step()
+        first = torch.cuda.Event()
+        first.record()
+        t_w = time.perf_counter()
+        while not first.query():
+            if time.perf_counter() - t_w > deadline:
+                print(f"[bench] rank {rank} (device {dev}, pid {os.getpid()}): the first all-gather did not complete within {deadline:.0f} s "
+                      f"-- {world} ranks expected, backend {backend}", file=sys.stderr, flush=True)
+                os._exit(3)
+            time.sleep(0.002)
+        print(f"[bench] rank {rank}: first collective done after {time.perf_counter() - t_w:.2f}s", file=sys.stderr, flush=True)
     for _ in range(args.warmup):
         step()
     events = not args.no_kernel_events

@@ -223,6 +223,14 @@ int tapclip_build_prompts(const float* ctx, const float* tok, const float* attri
                           int32_t attr_cols, int32_t n, int32_t P, int32_t L, int32_t D, float* out,
                           tapclip_stream_t stream);
 
+/* Backward of tapclip_build_prompts towards the context tokens -- the last torch arithmetic of the training forward
+ * (reference train.py:99-105 differentiates models/prompt_adjustor.py:35-36 and the torch.cat of model_wrapper.py:69 by
+ * autograd): d_ctx[n, t, :] = d_out[n, t, :] * attribution[n, t] for t < P (attribution NULL: a plain copy of those rows).
+ * The attribution is a constant of the step (the reference's hook detaches it, models/clip_wrapper.py:36) and the token rows
+ * belong to the frozen bank.  d_out [n,P+L,D], d_ctx [n,P,D]. */
+int tapclip_build_prompts_backward(const float* d_out, const float* attribution, int32_t attr_cols, int32_t n, int32_t P,
+                                   int32_t L, int32_t D, float* d_ctx, tapclip_stream_t stream);
+
 /* ---- `PromptAdjustor('gate' | 'residual')` (reference models/prompt_adjustor.py:13-25,38-44; no reference script selects them)
  * fused with the same two concatenations: a = attribution[n, t]; h = relu(w1 a + b1) with w1, b1 [64] (nn.Linear(1, 64));
  *   TAPCLIP_ADJUST_GATE:     out[n, t] = ctx[n, t] * sigmoid(w2 . h + b2)      w2 [64] (nn.Linear(64, 1).weight), b2 [1]
@@ -284,12 +292,19 @@ int tapclip_mx8_gemm(const uint8_t* a_q, const uint8_t* a_scale, int64_t M, int6
  * its TAPCLIP_COMM_ID_BYTES bytes to the other ranks out of band; every rank then calls tapclip_comm_create (collective,
  * on the HIP device it will use) and tapclip_allgather(send [bytes_per_rank] -> recv [world * bytes_per_rank], rank-major)
  * on its stream.  A thin layer over RCCL, which is opened at the first call (no link-time dependency).  The Python side
- * of this repository uses torch.distributed for the same step (tap-clip_amd/dist.py). */
+ * of this repository uses torch.distributed for the same step (tap-clip_amd/dist.py).
+ * tapclip_allgather returns the ENQUEUE status.  tapclip_comm_check(comm) is the non-blocking query of what happened since
+ * (ncclCommGetAsyncError): TAPCLIP_OK while the communicator is healthy or still working; on an asynchronous RCCL error -- a
+ * peer that died, a link error -- TAPCLIP_EHIP with the rank and RCCL's text in tapclip_last_error(), after ABORTING the
+ * communicator (ncclCommAbort) so that the stream queued behind the collective can drain; every later call on it returns
+ * TAPCLIP_ESTATE.  Call it when the event recorded behind a gather has completed -- or while polling that event with a
+ * deadline: a collective whose peer is gone never completes by itself.  tapclip_allgather checks before it enqueues. */
 typedef struct tapclip_comm tapclip_comm_t;
 #define TAPCLIP_COMM_ID_BYTES 128
 int tapclip_comm_unique_id(void* id_out);
 int tapclip_comm_create(const void* id, int32_t rank, int32_t world, tapclip_comm_t** out);
 int tapclip_allgather(tapclip_comm_t* comm, const void* send, void* recv, size_t bytes_per_rank, tapclip_stream_t stream);
+int tapclip_comm_check(tapclip_comm_t* comm);
 void tapclip_comm_destroy(tapclip_comm_t* comm);
 
 /* ---- behaviour switches of a tower handle.

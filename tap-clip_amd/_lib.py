@@ -48,6 +48,7 @@ SYMBOLS = [
     ("tapclip_embed_tokens", _i32, [_p, _p, _i32, _i32, _i32, _p, _p]),
     ("tapclip_attribution", _i32, [_p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     ("tapclip_build_prompts", _i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
+    ("tapclip_build_prompts_backward", _i32, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     ("tapclip_build_prompts_mlp", _i32, [_i32, _p, _p, _p, _i32, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
     ("tapclip_logits", _i32, [_p, _p, _f32, _i32, _i32, _i32, _p, _p]),
     ("tapclip_preprocess_u8", _i32, [_p, _p, _i32, _i32, _p, _p, _p, _p]),
@@ -59,6 +60,7 @@ SYMBOLS = [
     ("tapclip_comm_unique_id", _i32, [_p]),
     ("tapclip_comm_create", _i32, [_p, _i32, _i32, C.POINTER(_p)]),
     ("tapclip_allgather", _i32, [_p, _p, _p, _sz, _p]),
+    ("tapclip_comm_check", _i32, [_p]),
     ("tapclip_comm_destroy", None, [_p]),
     ("tapclip_tower_set_flag", _i32, [_p, _i32, _i32]),
     ("tapclip_tower_get_flag", _i32, [_p, _i32, C.POINTER(_i32)]),

@@ -309,6 +309,20 @@ __global__ void build_prompts_kernel(const float* __restrict__ ctx, const float*
   out[i] = v;
 }
 
+// backward of the same op towards the context tokens (the token rows are the frozen bank's, the attribution is a constant: the
+// reference's hook detaches it, models/clip_wrapper.py:36): d_ctx[n, t, :] = d_out[n, t, :] * attr[n, t], t < P
+__global__ void build_prompts_bwd_kernel(const float* __restrict__ d_out, const float* __restrict__ attr, int attr_cols, int P, int L,
+                                         int D, int64_t total, float* d_ctx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t n = i / ((int64_t)P * D);
+  const int64_t rem = i - n * P * D;
+  const int t = (int)(rem / D), c = (int)(rem - (int64_t)t * D);
+  float v = d_out[(n * (P + L) + t) * D + c];
+  if (attr != nullptr) v *= attr[n * attr_cols + (attr_cols == 1 ? 0 : t)];
+  d_ctx[i] = v;
+}
+
 // ---- K13: logits[b, c] = scale * <img[b], txt[c]> (reference models/model_wrapper.py:79,83).
 // Sixteen lanes per logit (float4 loads, 256 contiguous bytes per group and step), xor-shuffle reduction: at
 // 256 x 65 logits one thread per logit was a 24-us chain of 128 dependent FMAs on 6 % of the chip.
@@ -470,6 +484,13 @@ hipError_t launch_build_prompts(const float* ctx, const float* tok, const float*
                                 int32_t P, int32_t L, int32_t D, float* out, hipStream_t s) {
   const int64_t total = (int64_t)n * (P + L) * D;
   hipLaunchKernelGGL(build_prompts_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, ctx, tok, attr, attr_cols, P, L, D, total, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_build_prompts_backward(const float* d_out, const float* attr, int32_t attr_cols, int32_t n, int32_t P, int32_t L,
+                                         int32_t D, float* d_ctx, hipStream_t s) {
+  const int64_t total = (int64_t)n * P * D;
+  hipLaunchKernelGGL(build_prompts_bwd_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, d_out, attr, attr_cols, P, L, D, total, d_ctx);
   return hipGetLastError();
 }
 

@@ -207,6 +207,8 @@ hipError_t launch_attribution(const float* amap, int32_t n, int32_t T, int32_t T
                               float* out, hipStream_t s);
 hipError_t launch_build_prompts(const float* ctx, const float* tok, const float* attr, int32_t attr_cols,
                                 int32_t n, int32_t P, int32_t L, int32_t D, float* out, hipStream_t s);
+hipError_t launch_build_prompts_backward(const float* d_out, const float* attr, int32_t attr_cols, int32_t n, int32_t P, int32_t L,
+                                         int32_t D, float* d_ctx, hipStream_t s);
 // PromptAdjustor 'gate' (method 1: w2 [64], b2 [1]) / 'residual' (method 2: w2 [D, 64], b2 [D]) + the concatenations
 hipError_t launch_build_prompts_mlp(int method, const float* ctx, const float* tok, const float* attr, int32_t attr_cols, const float* w1,
                                     const float* b1, const float* w2, const float* b2, int32_t n, int32_t P, int32_t L, int32_t D, float* out,

@@ -1268,6 +1268,14 @@ int tapclip_build_prompts(const float* ctx, const float* tok, const float* attri
   return TAPCLIP_OK;
 }
 
+int tapclip_build_prompts_backward(const float* d_out, const float* attribution, int32_t attr_cols, int32_t n, int32_t P, int32_t L,
+                                   int32_t D, float* d_ctx, tapclip_stream_t stream) {
+  if (!d_out || !d_ctx || n <= 0 || P <= 0 || L < 0 || D <= 0) return fail(TAPCLIP_EINVAL, "bad build_prompts_backward arguments");
+  if (attribution && attr_cols != P && attr_cols != 1) return fail(TAPCLIP_EINVAL, "attribution must be [n,%d] or [n,1], got %d columns", P, attr_cols);
+  HIP_TRY(launch_build_prompts_backward(d_out, attribution, attr_cols, n, P, L, D, d_ctx, static_cast<hipStream_t>(stream)));
+  return TAPCLIP_OK;
+}
+
 int tapclip_build_prompts_mlp(int32_t method, const float* ctx, const float* tok, const float* attribution, int32_t attr_cols,
                               const float* w1, const float* b1, const float* w2, const float* b2, int32_t n, int32_t P, int32_t L, int32_t D,
                               float* out, tapclip_stream_t stream) {
@@ -1391,6 +1399,8 @@ struct RcclApi {
   int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*CommGetAsyncError)(void*, int*) = nullptr;  // optional (RCCL has had both since 2.4): without them tapclip_comm_check
+  int (*CommAbort)(void*) = nullptr;                // reports what the enqueue status told, nothing more
 };
 RcclApi& rccl() {
   static RcclApi api = [] {
@@ -1405,6 +1415,8 @@ RcclApi& rccl() {
       a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(a.handle, "ncclAllGather"));
       a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.handle, "ncclCommDestroy"));
       a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.handle, "ncclGetErrorString"));
+      a.CommGetAsyncError = reinterpret_cast<decltype(a.CommGetAsyncError)>(dlsym(a.handle, "ncclCommGetAsyncError"));
+      a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(dlsym(a.handle, "ncclCommAbort"));
       if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.CommDestroy) a.handle = nullptr;
     }
     return a;
@@ -1450,8 +1462,30 @@ int tapclip_comm_create(const void* id, int32_t rank, int32_t world, tapclip_com
   return TAPCLIP_OK;
 }
 
+// The asynchronous state of a communicator, without blocking ("RCCL async-error query after the
+// all-gather").  ncclAllGather's own return value is the ENQUEUE status: a peer that died, a link error or a failed kernel shows
+// only here -- and a stream that waits on such a collective never finishes by itself.  On an error the communicator is ABORTED
+// (ncclCommAbort: its pending work is torn down so the caller's stream can drain) and is dead from then on.
+int tapclip_comm_check(tapclip_comm_t* comm) {
+  if (!comm) return fail(TAPCLIP_EINVAL, "null communicator");
+  if (!comm->nccl) return fail(TAPCLIP_ESTATE, "communicator of rank %d / %d was aborted after an RCCL error", comm->rank, comm->world);
+  const RcclApi& a = rccl();
+  if (!a.CommGetAsyncError) return TAPCLIP_OK;  // (nothing to ask)
+  int async = 0;
+  const int rc = a.CommGetAsyncError(comm->nccl, &async);
+  if (rc) return rccl_fail("ncclCommGetAsyncError", rc);
+  constexpr int kNcclInProgress = 7;  // ncclInProgress: a non-blocking communicator still working -- not an error
+  if (async == 0 || async == kNcclInProgress) return TAPCLIP_OK;
+  const char* what = a.GetErrorString ? a.GetErrorString(async) : "RCCL error";
+  if (a.CommAbort) (void)a.CommAbort(comm->nccl);
+  comm->nccl = nullptr;
+  return fail(TAPCLIP_EHIP, "RCCL reported an asynchronous error on rank %d of %d: %s (communicator aborted; destroy it and rebuild the group)",
+              comm->rank, comm->world, what);
+}
+
 int tapclip_allgather(tapclip_comm_t* comm, const void* send, void* recv, size_t bytes_per_rank, tapclip_stream_t stream) {
   if (!comm || !send || !recv) return fail(TAPCLIP_EINVAL, "null argument");
+  if (const int st = tapclip_comm_check(comm)) return st;  // an error of an EARLIER collective: do not queue behind it
   if (bytes_per_rank == 0) return TAPCLIP_OK;
   const int rc = rccl().AllGather(send, recv, bytes_per_rank, /* ncclChar */ 0, comm->nccl, static_cast<hipStream_t>(stream));
   return rc ? rccl_fail("ncclAllGather", rc) : TAPCLIP_OK;
@@ -1459,7 +1493,7 @@ int tapclip_allgather(tapclip_comm_t* comm, const void* send, void* recv, size_t
 
 void tapclip_comm_destroy(tapclip_comm_t* comm) {
   if (!comm) return;
-  if (comm->nccl) (void)rccl().CommDestroy(comm->nccl);
+  if (comm->nccl) (void)rccl().CommDestroy(comm->nccl);  // (an aborted communicator was released by ncclCommAbort)
   delete comm;
 }
 

@@ -333,6 +333,20 @@ def build_prompts(ctx: torch.Tensor, tok: torch.Tensor, attr: Optional[torch.Ten
     return out
 
 
+def build_prompts_backward(grad_out: torch.Tensor, prompt_len: int, attr: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """d(loss)/d(ctx) of `build_prompts`: grad_out[:, :P] * attr[..., None] (reference autograd through
+    models/prompt_adjustor.py:35-36 and the torch.cat of models/model_wrapper.py:69; the attribution is detached there)."""
+    g = grad_out.detach().to(torch.float32).contiguous()
+    n, T, D = g.shape
+    P = int(prompt_len)
+    a = None if attr is None else attr.detach().to(device=g.device, dtype=torch.float32).contiguous()
+    out = torch.empty(n, P, D, dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        _lib.check(_lib.load().tapclip_build_prompts_backward(_ptr(g), _ptr(a), 0 if a is None else a.shape[1], n, P, T - P, D,
+                                                              _ptr(out), _stream_ptr(g.device)))
+    return out
+
+
 def build_prompts_mlp(ctx: torch.Tensor, tok: torch.Tensor, attr: torch.Tensor, adjustor) -> torch.Tensor:
     """cat([PromptAdjustor('gate' | 'residual')(ctx, attr), tok], dim=1) in one kernel (reference
     models/prompt_adjustor.py:38-44, models/model_wrapper.py:68-69); forward only, the adjustor's weights as they are."""

@@ -58,6 +58,23 @@ class _TextTowerFn(torch.autograd.Function):
         return ctx.tower.backward_saved(saved, g_hidden, tail_run=ctx.tail_run), None, None
 
 
+class _BuildPromptsFn(torch.autograd.Function):
+    """cat([ctx * attribution[..., None], tok], 1) (reference prompt_adjustor.py:35-36, model_wrapper.py:69) as ONE kernel each
+    way: with it the training forward issues no torch arithmetic between the towers (`PromptAdjustor('scale')` only; the
+    attribution is a constant of the step, as the reference's hook detaches it)."""
+
+    @staticmethod
+    def forward(ctx, context, tok, attribution):
+        ctx.P = context.shape[1]
+        ctx.save_for_backward(attribution)
+        return engine.build_prompts(context, tok, attribution)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (attribution,) = ctx.saved_tensors
+        return engine.build_prompts_backward(grad_out, ctx.P, attribution), None, None
+
+
 class _LogitsFn(torch.autograd.Function):
     """exp(logit_scale) * img @ txt.T (reference model_wrapper.py:79,83); img carries no gradient (frozen tower)."""
 
@@ -297,7 +314,10 @@ class FullModel(nn.Module):
                     attn_map = attn_map.unsqueeze(1)
                 attribution = self.attribution_monitor(attn_map)
             ctx = pl.stacked_context()                                   # differentiable w.r.t. every context_bank entry
-            adjusted = torch.cat([self.prompt_adjustor(ctx, attribution), tok], dim=1)
+            if self.prompt_adjustor.method == "scale" and ctx.is_cuda:
+                adjusted = _BuildPromptsFn.apply(ctx, tok, attribution)
+            else:  # 'gate' / 'residual' carry trainable nets of their own: the torch modules and their autograd
+                adjusted = torch.cat([self.prompt_adjustor(ctx, attribution), tok], dim=1)
             text_feat = _TextTowerFn.apply(adjusted, clip, run)
         with torch.no_grad():
             image_feat, labels = self._image_features_end(image_feat, labels, side)

@@ -148,6 +148,7 @@ assert lib.tapclip_comm_unique_id(None) == _lib.EINVAL
 assert lib.tapclip_comm_create(None, 0, 1, C.byref(comm)) == _lib.EINVAL
 assert lib.tapclip_comm_create(idbuf, 2, 2, C.byref(comm)) == _lib.EINVAL and "bad rank" in err()
 assert lib.tapclip_allgather(None, dummy, dummy, 64, None) == _lib.EINVAL
+assert lib.tapclip_comm_check(None) == _lib.EINVAL and "null communicator" in err()
 lib.tapclip_comm_destroy(None)
 assert lib.tapclip_abi_version() == 1
 print("sanitized host paths ok")

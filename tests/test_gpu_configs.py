@@ -709,7 +709,16 @@ _lib.check(lib.tapclip_comm_create(idbuf, 0, 1, C.byref(comm)))
 x = torch.nn.functional.normalize(torch.randn(256, 512, device="cuda"), dim=-1)
 y = torch.zeros_like(x)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+_lib.check(lib.tapclip_comm_check(comm))
 _lib.check(lib.tapclip_allgather(comm, x.data_ptr(), y.data_ptr(), x.numel() * 4, st))
+done = torch.cuda.Event(); done.record()
+import time
+t0 = time.time()
+while not done.query():  # the poll a real exchange step uses: the async state while the gather's event is pending, with a deadline
+    _lib.check(lib.tapclip_comm_check(comm))
+    assert time.time() - t0 < 60, "all-gather did not complete"
+    time.sleep(1e-4)
+_lib.check(lib.tapclip_comm_check(comm))
 torch.cuda.synchronize()
 assert torch.equal(x, y)
 lib.tapclip_comm_destroy(comm)

@@ -897,3 +897,20 @@ def test_text_feature_cache_is_opt_in_and_invalidates():
         assert not torch.equal(c, a)
         model.cache_text_features = False
         assert torch.equal(model(images)["logits"], c)
+
+
+def test_build_prompts_backward_vs_autograd(eng):
+    """tapclip_build_prompts_backward against torch autograd through the reference's two ops (prompt_adjustor.py:35-36 multiply,
+    model_wrapper.py:69 torch.cat): bit-equal (one fp32 multiply per element either way); [n,P] and literal [n,1] attribution."""
+    n, P, L, D = 5, 16, 77, 512
+    ctx = synth.normal([n, P, D], 41, "bp.ctx").to(DEV).requires_grad_(True)
+    tok = synth.normal([n, L, D], 41, "bp.tok", 0.02).to(DEV)
+    g = synth.normal([n, P + L, D], 41, "bp.g").to(DEV)
+    for cols in (P, 1):
+        a = torch.softmax(synth.normal([n, cols], 41, f"bp.a{cols}"), dim=-1).to(DEV) if cols > 1 else torch.full((n, 1), 0.75, device=DEV)
+        ref_out = torch.cat([ctx * a.unsqueeze(-1) if cols > 1 else ctx * a.view(n, 1, 1), tok], dim=1)
+        (ref_grad,) = torch.autograd.grad(ref_out, ctx, g)
+        got = eng.build_prompts_backward(g, P, a)
+        assert torch.equal(got, ref_grad)
+        assert torch.equal(eng.build_prompts(ctx, tok, a), ref_out.detach())
+    assert torch.equal(eng.build_prompts_backward(g, P, None), g[:, :P])
