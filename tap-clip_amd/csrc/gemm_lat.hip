@@ -91,8 +91,10 @@ __global__ __launch_bounds__(256, 1) void gemm_lat_kernel(GemmArgs g) {
   };
 
   // accumulators start at the bias and take the k-steps in ascending order, the three split products of a k-step in the
-  // order hi.hi, A_lo.W_hi, A_hi.W_lo -- exactly what the tiled kernels do (gemm256.hip, gemm.hip), so a row's bits do not
-  // depend on which kernel its launch's row count selects (the batch-invariance tests compare across that boundary)
+  // order hi.hi, A_lo.W_hi, A_hi.W_lo per 32-deep step -- exactly what gemm256.hip does, so a row's bits do not depend on
+  // which of THESE TWO kernels its launch's row count selects (the batch-invariance tests compare across that boundary).
+  // (gemm.hip, the fallback of TAPCLIP_GEMM_LAT=0 / TAPCLIP_GEMM_TILE=128 / operands past the 32-bit offset limit, stages
+  // 64-deep slices and runs each product over k[0:64] before the next: another fp32 summation order, equal to rounding only.)
   // (the bias is loaded BEFORE the ring's first DMA is issued: vmcnt retires in order, and a load behind the prologue's
   // stages would make its first use wait for all of them)
   f32x4_t acc[NJ][MI];
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256, 1) void gemm_lat_kernel(GemmArgs g) {
 
 template <int EPI, bool SPLIT, int BM, int BN>
 hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
-  constexpr int NS = SPLIT ? ((BM + BN) >= 256 ? 4 : 6) : 8;  // <= 128 KiB of ring
+  constexpr int NS = SPLIT ? ((BM + BN) >= 256 ? 4 : 6) : 8;  // <= 144 KiB of ring (split 128 x 64: 6 stages of 24 KiB; every other shape <= 128 KiB)
   constexpr int smem_bytes = NS * (SPLIT ? 2 : 1) * (BM + BN) * BKS * 2;
   static bool attr_set = false;
   if (!attr_set) {

@@ -270,6 +270,22 @@ class FullModel(nn.Module):
     def _tail_run(self) -> int:
         return self.prompt_learner.tail_run() if self.tie_padding else 1
 
+    def check_tied_padding(self) -> None:
+        """Raise if the text tower found the tied-padding claim false (the rows FullModel said were identical were not: a
+        direct edit of `prompt_learner.token_bank`, a user hook that changes rows in front of the transformer).  The library
+        then poisons its outputs with NaN -- safe, but a NaN loss does not say why.  One device-to-host read: call it where
+        the host synchronises anyway (the evaluation loops do at their end; `forward` does when its loss is not finite).
+        The cached run length is dropped, so the next forward measures the token bank again."""
+        if not self.tie_padding or not hasattr(self.clip, "_text"):
+            return
+        if self.clip._text.tied_violations():
+            self.prompt_learner._tail_run = None
+            self.prompt_learner._tok_cache = None
+            raise RuntimeError("tied padding rows: the text tower was told that the last `tail_run` rows of every prompt are identical "
+                               "(FullModel(tie_padding=True), PromptLearner.tail_run()) and found them different -- its outputs since "
+                               "then are NaN on purpose.  Rebuild the token bank with PromptLearner.refresh_token_bank() after editing "
+                               "it, or construct FullModel(tie_padding=False) / set TAPCLIP_TIE_PADDING=0")
+
     def _forward_literal(self, images: torch.Tensor) -> torch.Tensor:
         """The reference loop nest as written (model_wrapper.py:47-83), on the HIP towers."""
         pl, clip = self.prompt_learner, self.clip

@@ -17,8 +17,9 @@ def _count(model, dataloader, device):
     Data-parallel FullModel (`gather_images=True`): every rank holds the GLOBAL logits (rank-major rows), so the rank's
     labels are gathered the same way and every rank counts the same global totals.  Local batches may differ in length
     (an evaluation loader sharded without padding ends in a short batch on some ranks): embeddings and labels are
-    gathered with their row counts exchanged first (`dist.all_gather_rows(ragged=True)`).  Ranks must still run the same
-    NUMBER of batches -- a rank whose shard is exhausted early must feed empty batches -- and a sampler that pads its
+    gathered with their row counts exchanged first (`dist.all_gather_rows(ragged=True)`).  Ranks may also run different
+    NUMBERS of batches: the loop agrees on the longest shard and feeds empty batches on the ranks that ran out
+    (`_synced_batches`; a loader without a reliable length agrees batch by batch).  A sampler that pads its
     shards with DUPLICATE samples (torch's DistributedSampler with drop_last=False) has those duplicates counted: shard
     without padding (e.g. indices[rank::world]) to get the single-process figures."""
     model.eval()
@@ -32,6 +33,10 @@ def _count(model, dataloader, device):
     finally:
         if gather:
             model.ragged_batches = was_ragged
+    # the counts were just read on the host: the one place where asking the text tower whether its tied-padding claim held
+    # costs nothing (FullModel.check_tied_padding raises with the cause; a false claim makes every logit NaN on purpose)
+    if hasattr(model, "check_tied_padding"):
+        model.check_tied_padding()
     return correct, total
 
 
@@ -61,8 +66,13 @@ def _synced_batches(model, dataloader, device):
         return torch.zeros((0,) + tuple(shape)), torch.zeros(0, dtype=torch.int64)
 
     it = iter(dataloader)
-    if hasattr(dataloader, "__len__"):
-        longest = agree_max(len(dataloader))      # ONE collective for the whole loop
+    try:  # (every torch DataLoader HAS __len__; over an IterableDataset it raises TypeError or is only an estimate)
+        n_mine = len(dataloader)
+    except TypeError:
+        n_mine = -1
+    # ONE collective decides the mode for everybody: a rank without a usable length turns the whole loop to per-batch agreement
+    if agree_max(1 if n_mine < 0 else 0) == 0:
+        longest = agree_max(n_mine)                # ONE collective for the sized part of the loop
         for _ in range(longest):
             batch = next(it, None)
             if batch is None:
@@ -70,8 +80,9 @@ def _synced_batches(model, dataloader, device):
             else:
                 shape = tuple(batch[0].shape[1:])
             yield batch
-        return
-    while True:                                    # a loader without a length: one tiny collective per batch
+        # a length that under-counted (an estimate): keep agreeing until EVERY rank's iterator is exhausted -- batches beyond
+        # the agreed length are evaluated, not dropped
+    while True:                                    # a loader without a (reliable) length: one tiny collective per batch
         batch = next(it, None)
         if agree_max(0 if batch is None else 1) == 0:
             return

@@ -203,3 +203,33 @@ def test_token_bank_change_re_measures_the_run():
         out = model(images)["logits"]
     assert out.shape == (2, len(g["class_names"]) + 1) and torch.isfinite(out).all()
     assert not model.clip._text.tied_violations()
+
+
+def test_direct_token_bank_edit_is_diagnosed_not_just_nan():
+    """`token_bank` is a public dict; an edit that goes around add_class_prompt / refresh_token_bank leaves the cached
+    run length stale, the library poisons its outputs (NaN, by design) -- and `check_tied_padding` (called by the evaluation loops
+    at their end) names the cause and drops the cache, so that the next forward measures the bank again and is finite."""
+    from test_gpu_parity import _build_full
+    from tap_clip_amd.utils import eval_metrics
+
+    g = golden("fullmodel_intended_tiny")
+    model, images = _build_full("tiny", g, "intended", "bf16")
+    with torch.no_grad():
+        assert torch.isfinite(model(images)["logits"]).all()
+    model.check_tied_padding()  # nothing to report
+    pl = model.prompt_learner
+    name = next(iter(pl.token_bank))
+    edited = pl.token_bank[name].clone()
+    edited[..., -3, :] += 1.0      # one of the "identical" padding rows is no longer identical
+    pl.token_bank[name] = edited
+    pl._tok_cache = None           # (the stacked copy is rebuilt from the dict; the run length measured before is now stale)
+    with torch.no_grad():
+        bad = model(images)["logits"]
+    assert torch.isnan(bad).any()
+    with pytest.raises(RuntimeError, match="tie_padding"):
+        model.check_tied_padding()
+    with torch.no_grad():
+        again = model(images)["logits"]  # the run was re-measured: the edited row is outside it now
+    assert torch.isfinite(again).all()
+    labels = torch.zeros(images.shape[0], dtype=torch.int64)
+    eval_metrics.evaluate_accuracy(model, [(images.cpu(), labels)], DEV)  # (and the loop's own check passes)

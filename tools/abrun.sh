@@ -1,6 +1,7 @@
 #!/bin/bash
 # on the GPU box: interleaved pipeline A/B of library variants (tools/libtapclip_<v>.so; "cur" = the in-tree library)
 cp tap-clip_amd/csrc/libtapclip.so /tmp/cur.so
+trap 'cp /tmp/cur.so tap-clip_amd/csrc/libtapclip.so' EXIT  # an interrupted run must not leave an A/B build installed
 for round in 1 2; do for v in "$@"; do
   if [ $v = cur ]; then cp /tmp/cur.so tap-clip_amd/csrc/libtapclip.so; else cp tools/libtapclip_$v.so tap-clip_amd/csrc/libtapclip.so; fi
   echo "== $v"
