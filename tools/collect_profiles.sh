@@ -1,20 +1,20 @@
 #!/bin/bash
 # Collects the round's profile set on the GPU box (run through gpurun from the repo root), in two parts (a gpurun call is
 # limited to 20 minutes):
-#   tools/collect_profiles.sh <tag> main    rocprofv3 kernel stats, PMC traffic (bf16 headline AND the fp16 parity mode) and SQ
+#   tools/collect_profiles.sh <tag> main    rocprofv3 kernel stats, PMC traffic (the fp16 headline AND the bf16 mode) and SQ
 #                                           counters of the ViT-B/16 headline, then the bench line itself
 #   tools/collect_profiles.sh <tag> vitl    BASELINE configs[4] at its per-GPU size in fp8 / bf16 / fp16 (seeded host weights)
 # -> gpurun_out/prof_<tag>/..., summaries copied by hand into profiles/
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 PART=${2:-main}
 R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-FAST="--steps 3 --warmup 1 --no-cpu-baseline --no-full-forward --no-kernel-events --no-precisions --no-input-side --no-configs4"
+FAST="--steps 3 --warmup 1 --no-cpu-baseline --no-full-forward --no-kernel-events --no-precisions --no-input-side --no-configs4 --no-sustained --no-batch-sweep"
 if [ $PART = main ]; then
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $R/bench.py --no-configs4 > $OUT/bench_under_trace.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $R/bench.py --no-configs4 --sustained-seconds 1 --no-batch-sweep > $OUT/bench_under_trace.json 2> $OUT/stats.err
 echo "trace done"
 for P in bf16 fp16; do
   S=""; [ $P = fp16 ] && S="_fp16"
@@ -25,7 +25,7 @@ done
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/sq -o sq -- python3 $R/bench.py $FAST > /dev/null 2> $OUT/sq.err
 echo "sq done"
 cd $R
-python3 tools/trace_family.py $OUT/stats $OUT/gemm_family_trace_summary.json bf16
+python3 tools/trace_family.py $OUT/stats $OUT/gemm_family_trace_summary.json fp16
 python3 tools/pmc_traffic.py $OUT/fetch $OUT/write $OUT/pmc_traffic_bench.json
 python3 tools/pmc_traffic.py $OUT/fetch_fp16 $OUT/write_fp16 $OUT/pmc_traffic_bench_fp16.json
 python3 tools/pmc_sq.py $OUT/sq $OUT/pmc_sq_bench.json
