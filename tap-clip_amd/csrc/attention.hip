@@ -312,7 +312,8 @@ __global__ __launch_bounds__(512, (NKT % 2) ? 6 : 1) void attn_kernel(AttnArgs a
 #endif
 }
 
-// ---- long sequences (T > 256, e.g. ViT-L/14@336: 577 tokens): the same transposed products, flash style.
+// ---- long sequences (T > 256, e.g. ViT-L/14@336: 577 tokens): the same transposed products, flash style.  Since round 5 this
+// kernel serves the split-bf16 and the causal case only; 16-bit operands without a mask run attention_long.hip (launch_attention).
 // Grid (sequence*head, query chunk); the workgroup walks the keys in blocks of KB*16, staging one K/V block
 // at a time in LDS; each wave owns QT 16-query tiles and keeps their running max m, partial row sum l
 // (lane-local: the rescale factor is row-uniform, so the 4 lanes of a query are reduced once at the end)
