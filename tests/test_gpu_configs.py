@@ -782,6 +782,47 @@ def test_image_tower_is_bit_stable_beside_a_busy_second_stream(eng, name, batch,
         assert differ == 0, f"{name} batch {batch} {precision} beside {label}: {differ}/{n_it} runs differ from the solo run"
 
 
+@pytest.mark.parametrize("precision", ["fp16", "bf16", "fp8"])
+def test_long_sequence_tower_is_bit_stable_beside_a_busy_second_stream(eng, precision):
+    """The same for the 577-token geometry (ViT-L/14@336 widths, 2 blocks, batch 16): the LDS-DMA attention kernel of round 5
+    (csrc/attention_long.hip) keeps hand-counted vmcnt / lgkmcnt queues and runs VALU arithmetic on MFMA accumulators beside its
+    own LDS-fed MFMAs -- with packed-fp32 ops in it 15-25 of 1.18 M rows came out wrong per launch, other rows every run
+    (profiles/r05_flash2_packed_rescale.txt).  Every run beside a busy neighbour must equal the solo run bit for bit."""
+    cfg = configs.ClipDims("L14-336-2blocks", 768, 336, 14, configs.TowerDims(1024, 2, 16, 4096), configs.TowerDims(512, 2, 8, 2048), vocab=512)
+    sd = synth.make_state_dict(cfg, seed=2)
+    images = synth.make_images(16, cfg, 0).to(DEV)
+    ctx, tok = synth.make_prompts(10, 5, cfg, seed=1)
+    prompts = torch.cat([ctx, tok], 1).to(DEV)
+    text = eng.TextTower(cfg, sd, DEV, "bf16x3")
+    tower = eng.VisionTower(cfg, sd, DEV, precision, prune_last_block=False)
+    big = torch.randn(2048, 2048, device=DEV, dtype=torch.bfloat16)
+    base = tower.encode_image(images, normalize=True).clone()
+    assert bool(torch.isfinite(base).all())
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+
+    def neighbour_text():
+        text.forward(prompts, want_hidden=False, want_mean=True)
+        text.forward(prompts)
+
+    def neighbour_matmul():
+        for _ in range(20):
+            big @ big
+
+    n_it = int(os.environ.get("TAPCLIP_STABILITY_ITERS", "10"))  # (soak runs: 200)
+    for label, nb in (("nothing", lambda: None), ("text tower bf16x3", neighbour_text), ("torch matmul", neighbour_matmul)):
+        differ = 0
+        for _ in range(n_it):
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                e = tower.encode_image(images, normalize=True)
+            nb()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            differ += int(not torch.equal(e, base))
+        assert differ == 0, f"577 tokens {precision} beside {label}: {differ}/{n_it} runs differ from the solo run"
+
+
 def test_text_tower_is_bit_stable_beside_the_image_tower(eng):
     """The other direction: the text tower (bf16 and split-bf16; its LayerNorms run beside the image tower's GEMMs in
     FullModel(overlap_towers=True)) on the main stream while a side stream runs the image tower."""
