@@ -19,9 +19,10 @@
 namespace tapclip {
 namespace {
 
-// ---- What the ablation of the first flash kernel showed and what its traffic looked like decide the shape.
-// What the ablation of the kernel above showed (profiles/r04_flash_attention_ablation.txt: 97 of 164 us were neither VALU nor
-// MFMA) and what its traffic looked like decide the shape:
+// ---- What the ablation of the first flash kernel showed (profiles/r04_flash_attention_ablation.txt: 97 of its 164 us were neither
+// VALU nor MFMA) and what its traffic looked like (profiles/r05_pmc_attention_long.json: 1.06 GB fetched per launch for a 454 MB
+// q|k|v) decide the shape.  Measured at ViT-L/14@336, batch 128: 332-346 -> 258 us per launch (tools/attn_bench;
+// profiles/r05_attn_bench_*.log, r05_flash2_ablation.log; the steps in between: docs/HISTORY.md Part A (a)).
 //  * K/V blocks (64 keys) go global -> LDS by LDS-DMA into a ring of NS stages, ONE barrier per block, the DMA of block
 //    j + NS - 1 in flight under the products of block j -- no staging registers, no second barrier, no LDS store issue.
 //    The DMA writes lane-linear 1-KiB pieces (8 key rows), so both images are swizzled on the SOURCE side at 16-byte
@@ -42,6 +43,12 @@ namespace {
 //  * LAZY > 0: the running maximum of a query moves only when a block's maximum exceeds it by more than LAZY (in log2 units;
 //    un-normalised probabilities then reach 2^LAZY instead of 1 -- the same relative precision in a floating-point P, and
 //    65504 is far away), so the O accumulators are rescaled in the first block and after that almost never.
+//  * two things hipcc must be kept from: (1) it puts `s_waitcnt vmcnt(0)` in front of the ds_read_tr BUILTIN while an LDS-DMA is
+//    outstanding (no alias information: the read could be of what the DMA writes), so the transposed V reads are inline asm with
+//    hand-counted lgkmcnt; (2) global loads still pending at the loop's entry (the Q fragments) turn their first use inside the
+//    loop into a vmcnt(0) in EVERY iteration, draining the DMAs issued behind them -- the fragments are "consumed" by an empty
+//    asm before the first DMA.  And none of its geometries may spill (tests/test_build_resources.py): scratch traffic would sit in
+//    the hand-counted vmcnt queue.
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 template <int N>
