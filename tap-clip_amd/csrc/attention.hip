@@ -22,6 +22,9 @@
 
 #include "common.h"
 #include "kernels.h"
+#ifndef TAPCLIP_TU_NO_NANS
+#error "attention.hip is built with -fno-honor-nans -DTAPCLIP_TU_NO_NANS (csrc/Makefile): its maxima are plain fmaxf"
+#endif
 #include "attn_store.h"
 
 namespace tapclip {
@@ -40,17 +43,15 @@ __device__ __forceinline__ bf16x8_t tr_pair(const uint8_t* base0, const uint8_t*
 // ---- softmax arithmetic of the three kernels below.  The score loop is VALU-issue bound (a flash step of 16 scores per lane was
 // 73 plain VALU ops + 17 v_exp_f32 beside 16 MFMAs), and a third of those ops were avoidable:
 //  * fmaxf() has IEEE maxNum semantics, so hipcc canonicalises every MFMA output in front of it (v_max_f32 x, x, x: one extra op
-//    per score); the raw v_max3_f32 folds two scores per instruction and needs none.  (NaN scores propagate differently --
-//    they do not occur: the operands are finite and masked scores are -inf.)
+//    per score) -- unless it may assume there are no NaNs: this file is compiled with -fno-honor-nans (Makefile; the operands are
+//    finite, masked scores are -inf), and the nested fmaxf below become v_max3_f32, two scores per instruction.  (Rounds 3-5 had an
+//    asm statement of raw v_max3_f32 here.  hipcc does not pad an asm statement for the MFMA -> VALU read hazard -- gfx950 has no
+//    interlock there -- and in attention_long.hip such a statement read scores four instructions after their MFMA:
+//    profiles/r05_flash2_asm_hazard.txt.  No asm statement of this library reads an MFMA result now.)
 //  * exp argument and row sum two scores at a time: v_pk_fma_f32 / v_pk_add_f32 issue in the time of the scalar op.  Plain
 //    operand order only (the [0,1] op_sel encodings are the ones tests/test_abi.py rejects).
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float max3_raw(float a, float b, float c) {
-  float d;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
-__device__ __forceinline__ float fold_max(float m, const f32x4_t& v) { return max3_raw(max3_raw(m, v[0], v[1]), v[2], v[3]); }
+__device__ __forceinline__ float fold_max(float m, const f32x4_t& v) { return fmaxf(fmaxf(fmaxf(fmaxf(m, v[0]), v[1]), v[2]), v[3]); }
 // sum2[0] + sum2[1] as ONE scalar add (left to itself hipcc forms v_pk_add_f32 vX, vX, vX op_sel:[0,1], the pair swap)
 __device__ __forceinline__ float pair_sum(f32x2_t v) {
   float a = v[0];
@@ -642,6 +643,7 @@ struct AttnPoolArgs {
   bf16_t* out_hi;       // [n_seq, D]
   bf16_t* out_lo;
   int32_t n_seq, T, H, D;
+  int32_t q_log2;       // q carries log2(e) too (AttnArgs::q_log2): the scores are base-2 exponents
 };
 
 constexpr int POOL_MAX_T = 1024;
@@ -702,7 +704,7 @@ __global__ __launch_bounds__(256) void attn_pool_kernel(AttnPoolArgs a) {
   // ---- p_t = exp(s_t - max), sum (a wave's LDS accesses execute in order; the waves are independent)
   float sum = 0.f;
   for (int t = lane; t < a.T; t += 64) {
-    const float p = __expf(sc[wave][t] - mx);
+    const float p = a.q_log2 ? __builtin_amdgcn_exp2f(sc[wave][t] - mx) : __expf(sc[wave][t] - mx);
     sc[wave][t] = p;
     sum += p;
   }
@@ -748,10 +750,10 @@ __global__ __launch_bounds__(256) void attn_pool_kernel(AttnPoolArgs a) {
 }  // namespace
 
 hipError_t launch_attention_pooled(const bf16_t* q_hi, const bf16_t* q_lo, const bf16_t* qkv_hi, const bf16_t* qkv_lo, bf16_t* out_hi,
-                                   bf16_t* out_lo, int32_t n_seq, int32_t T, int32_t H, int32_t D, bool split, hipStream_t s) {
+                                   bf16_t* out_lo, int32_t n_seq, int32_t T, int32_t H, int32_t D, bool split, hipStream_t s, bool q_log2) {
   if (T <= 0 || T > POOL_MAX_T || D != H * 64 || n_seq <= 0 || !q_hi || !qkv_hi || !out_hi) return hipErrorInvalidValue;
   if (split && (!q_lo || !qkv_lo || !out_lo)) return hipErrorInvalidValue;
-  AttnPoolArgs a{q_hi, q_lo, qkv_hi, qkv_lo, out_hi, out_lo, n_seq, T, H, D};
+  AttnPoolArgs a{q_hi, q_lo, qkv_hi, qkv_lo, out_hi, out_lo, n_seq, T, H, D, q_log2 ? 1 : 0};
   const unsigned grid = (unsigned)((n_seq * H + 3) / 4);
   if (split) hipLaunchKernelGGL(attn_pool_kernel<true>, dim3(grid), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(attn_pool_kernel<false>, dim3(grid), dim3(256), 0, s, a);
@@ -766,8 +768,10 @@ hipError_t launch_attention(const AttnArgs& a, bool split, hipStream_t s) {
     if (a.probs != nullptr) return hipErrorInvalidValue;
     // 16-bit operands without a mask: the LDS-DMA kernel (round 5); split-bf16 and causal stay on the first flash kernel
     if (!split && !a.causal && flash2_cfg() != 1) return launch_flash2(a, s);  // attention_long.hip
+    if (a.q_log2) return hipErrorInvalidValue;  // (only that kernel reads base-2 scores)
     return split ? launch_flash<true>(a, s) : launch_flash<false>(a, s);
   }
+  if (a.q_log2) return hipErrorInvalidValue;
   return split ? dispatch<true>(a, s) : dispatch<false>(a, s);
 }
 

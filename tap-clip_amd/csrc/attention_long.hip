@@ -11,7 +11,12 @@
 // (DESIGN.md), on an encoding the round-2 probe -- a neighbour KERNEL on a second stream -- never saw fail.
 #include <cstdlib>
 
+#ifndef TAPCLIP_TU_NO_NANS
+#error "attention_long.hip is built with -fno-honor-nans -DTAPCLIP_TU_NO_NANS (csrc/Makefile): its maxima are plain fmaxf"
+#endif
+#ifndef TAPCLIP_AB_KEEP_PK  // (tools/: the A/B build that keeps them)
 #define TAPCLIP_TU_NO_PK_F32
+#endif
 #include "common.h"
 #include "kernels.h"
 #include "attn_store.h"
@@ -62,10 +67,6 @@ __device__ __forceinline__ void wait_vm() {
 #ifndef TAPCLIP_FLASH2_ABL
 #define TAPCLIP_FLASH2_ABL 0  // timing-only ablations (tools/Makefile attn_bench_alt): 1 no softmax VALU, 2 no MFMAs, 4 no LDS fragment reads, 8 no DMA / barriers after the first block
 #endif
-#ifndef TAPCLIP_FLASH2_PRESCALE
-#define TAPCLIP_FLASH2_PRESCALE 0  // (off: the extra rounding of q doubles the kernel's error against fp64 -- bf16 1.96e-3 -> 3.72e-3, half 2.2e-4 -> 4.6e-4 -- for 4 % of its time; exact only if log2(e) were folded into Wq at pack time)
-// 1: the Q fragments carry log2(e) and the score accumulators start at -m: exp2 takes the MFMA output as it is
-#endif
 #ifndef TAPCLIP_FLASH2_VAHEAD
 #define TAPCLIP_FLASH2_VAHEAD 1  // V fragments in flight ahead of their products (1 .. 3 of the 4 or 8 per step)
 #endif
@@ -87,35 +88,33 @@ struct Flash2Lane {
   int g;
 };
 
-// maximum of a query's NKT x 4 scores in this lane and of the same query's other three lanes: ONE asm statement per tile (a
-// statement per v_max3 made hipcc put an s_nop behind each: it does not look inside), raw v_max (fmaxf canonicalises its
-// operands first: two more ops per step)
+// maximum of a query's NKT x 4 scores in this lane and of the same query's other three lanes.  Plain fmaxf: this file is compiled
+// with -fno-honor-nans (Makefile; the operands are finite, masked scores are -inf), so hipcc neither canonicalises the MFMA
+// outputs first (one v_max x, x, x per score) nor keeps from folding two scores per v_max3_f32.  Until round 5 this was an asm
+// statement of raw v_max3_f32 -- and hipcc does NOT look inside an asm statement for the MFMA -> VALU read hazard: gfx950 has no
+// interlock there (an 8-pass MFMA's result may be read 11 wait states after its issue; the compiler pads its OWN instructions
+// only).  With one query tile per wave the statement followed the last product directly and read the last key tile's scores
+// four instructions later -- stale registers: a block maximum that missed its largest scores, P beyond the half range, NaN rows
+// (found with the base-2 build; profiles/r05_flash2_asm_hazard.txt).  No asm statement of this library reads an MFMA result now.
 template <int NKT>
 __device__ __forceinline__ float flash2_tile_max(const f32x4_t (&sc)[NKT]) {
-  float d;
-  if constexpr (NKT == 4) {
-    asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max3_f32 %0, %0, %8, %9\n\t"
-        "v_max3_f32 %0, %0, %10, %11\n\tv_max3_f32 %0, %0, %12, %13\n\tv_max3_f32 %0, %0, %14, %15\n\tv_max_f32 %0, %0, %16"
-        : "=&v"(d)
-        : "v"(sc[0][0]), "v"(sc[0][1]), "v"(sc[0][2]), "v"(sc[0][3]), "v"(sc[1][0]), "v"(sc[1][1]), "v"(sc[1][2]), "v"(sc[1][3]), "v"(sc[2][0]),
-          "v"(sc[2][1]), "v"(sc[2][2]), "v"(sc[2][3]), "v"(sc[3][0]), "v"(sc[3][1]), "v"(sc[3][2]), "v"(sc[3][3]));
-  } else if constexpr (NKT == 2) {
-    asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max_f32 %0, %0, %8"
-        : "=&v"(d)
-        : "v"(sc[0][0]), "v"(sc[0][1]), "v"(sc[0][2]), "v"(sc[0][3]), "v"(sc[1][0]), "v"(sc[1][1]), "v"(sc[1][2]), "v"(sc[1][3]));
-  } else {
-    static_assert(NKT == 1, "key tiles per step: 1, 2 or 4");
-    asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4" : "=&v"(d) : "v"(sc[0][0]), "v"(sc[0][1]), "v"(sc[0][2]), "v"(sc[0][3]));
+  float d = fmaxf(sc[0][0], sc[0][1]);
+  d = fmaxf(fmaxf(d, sc[0][2]), sc[0][3]);
+#pragma unroll
+  for (int kt = 1; kt < NKT; ++kt) {
+    d = fmaxf(fmaxf(d, sc[kt][0]), sc[kt][1]);
+    d = fmaxf(fmaxf(d, sc[kt][2]), sc[kt][3]);
   }
   auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(d), __float_as_uint(d), false, false);
-  asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(__uint_as_float(r16[0])), "v"(__uint_as_float(r16[1])));
+  d = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
   auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d), __float_as_uint(d), false, false);
-  asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(__uint_as_float(r32[0])), "v"(__uint_as_float(r32[1])));
-  return d;
+  return fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
 }
 
 // one key block (NKT 16-key tiles) for the NQ query tiles of a wave
-template <int QT, int NQ, int NKT, bool MASK>
+// QL2: q arrives in log2 units (AttnArgs::q_log2: log2(e) folded into Wq, bq at pack time) and the score accumulators start at
+// -m, so exp2 takes the MFMA output as it is
+template <int QT, int NQ, int NKT, bool MASK, bool QL2>
 __device__ __forceinline__ void flash2_step(const uint8_t* Kb, const uint8_t* Vb, const Flash2Lane& ln, const bf16x8_t (&qh)[QT][2],
                                             f32x4_t (&oc)[QT][4], float (&m)[QT], float (&l)[QT], f32x4_t (&nm)[QT], int key_base, int T, bool first) {
   constexpr float LOG2E = 1.44269504088896340736f;
@@ -142,7 +141,7 @@ __device__ __forceinline__ void flash2_step(const uint8_t* Kb, const uint8_t* Vb
       if (kt + KA < NKT) kread(kt + KA, (kt + KA) % (KA + 1));
 #pragma unroll
       for (int t = 0; t < NQ; ++t) {
-        sc[t][kt] = f2mm(kf[kt % (KA + 1)][0], qh[t][0], TAPCLIP_FLASH2_PRESCALE ? nm[t] : (f32x4_t{0.f, 0.f, 0.f, 0.f}));
+        sc[t][kt] = f2mm(kf[kt % (KA + 1)][0], qh[t][0], QL2 ? nm[t] : (f32x4_t{0.f, 0.f, 0.f, 0.f}));
         sc[t][kt] = f2mm(kf[kt % (KA + 1)][1], qh[t][1], sc[t][kt]);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -164,7 +163,7 @@ __device__ __forceinline__ void flash2_step(const uint8_t* Kb, const uint8_t* Vb
     float bm;
     if constexpr ((TAPCLIP_FLASH2_ABL & 1) != 0) bm = 0.f;
     else bm = flash2_tile_max<NKT>(sc[t]);  // finite: every block holds at least one key of the sequence
-    if constexpr (TAPCLIP_FLASH2_PRESCALE != 0) {
+    if constexpr (QL2) {
       // scores arrive as (q . k) log2e - m log2e (m[] holds m log2e, nm[] its negative as the accumulators' start; both 0 before
       // the first block): bm is the block's maximum RELATIVE to the running one.  It moves -- and everything held at the old
       // maximum is rescaled, once -- in the first block and whenever it would be exceeded by more than LAZY.
@@ -300,7 +299,7 @@ __device__ __forceinline__ void wait_vm_rt(int n) {
   }
 }
 
-template <int WAVES, int QT, int NS, int KB, int NQ>
+template <int WAVES, int QT, int NS, int KB, int NQ, bool QL2>
 __device__ __forceinline__ void flash2_run(const AttnArgs& a, uint8_t* smem, const Flash2Ctx& cx, const Flash2Lane& ln, const bf16x8_t (&qh)[QT][2],
                                            int tile0, int64_t row0, int head, int r) {
   constexpr int KEYS = KB * 16;                       // keys per block (KB 16-key tiles: 4 or 2)
@@ -341,7 +340,7 @@ __device__ __forceinline__ void flash2_run(const AttnArgs& a, uint8_t* smem, con
   f32x4_t oc[QT][4], nm[QT];
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
-    m[t] = TAPCLIP_FLASH2_PRESCALE ? 0.f : -INFINITY;
+    m[t] = QL2 ? 0.f : -INFINITY;
     nm[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     l[t] = 0.f;
 #pragma unroll
@@ -367,7 +366,7 @@ __device__ __forceinline__ void flash2_run(const AttnArgs& a, uint8_t* smem, con
   for (int kb = 0; kb < n_full; ++kb) {
     block_ready(kb);
     if (kb + NS - 1 < n_kb && !(TAPCLIP_FLASH2_ABL & 8)) dma_block(kb + NS - 1, slot == 0 ? NS - 1 : slot - 1);  // into the slot of block kb - 1
-    if constexpr (NQ > 0) flash2_step<QT, NQ, KB, false>(smem + slot * STAGE, smem + slot * STAGE + VOFF, ln, qh, oc, m, l, nm, kb * KEYS, T, kb == 0);
+    if constexpr (NQ > 0) flash2_step<QT, NQ, KB, false, QL2>(smem + slot * STAGE, smem + slot * STAGE + VOFF, ln, qh, oc, m, l, nm, kb * KEYS, T, kb == 0);
     slot = slot + 1 == NS ? 0 : slot + 1;
   }
   if (n_full < n_kb) {  // the last, partial block: 1 .. 63 keys (nothing left to request)
@@ -375,9 +374,9 @@ __device__ __forceinline__ void flash2_run(const AttnArgs& a, uint8_t* smem, con
     if constexpr (NQ > 0) {
       const uint8_t* Kb = smem + slot * STAGE;
       const int rem = T - n_full * KEYS;
-      if (rem <= 16) flash2_step<QT, NQ, 1, true>(Kb, Kb + VOFF, ln, qh, oc, m, l, nm, n_full * KEYS, T, n_full == 0);
-      else if (rem <= 32 || KB == 2) flash2_step<QT, NQ, 2, true>(Kb, Kb + VOFF, ln, qh, oc, m, l, nm, n_full * KEYS, T, n_full == 0);
-      else flash2_step<QT, NQ, (KB == 4 ? 4 : 2), true>(Kb, Kb + VOFF, ln, qh, oc, m, l, nm, n_full * KEYS, T, n_full == 0);
+      if (rem <= 16) flash2_step<QT, NQ, 1, true, QL2>(Kb, Kb + VOFF, ln, qh, oc, m, l, nm, n_full * KEYS, T, n_full == 0);
+      else if (rem <= 32 || KB == 2) flash2_step<QT, NQ, 2, true, QL2>(Kb, Kb + VOFF, ln, qh, oc, m, l, nm, n_full * KEYS, T, n_full == 0);
+      else flash2_step<QT, NQ, (KB == 4 ? 4 : 2), true, QL2>(Kb, Kb + VOFF, ln, qh, oc, m, l, nm, n_full * KEYS, T, n_full == 0);
     }
   }
 #pragma unroll
@@ -398,7 +397,7 @@ __device__ __forceinline__ void flash2_run(const AttnArgs& a, uint8_t* smem, con
 
 // WAVES waves per workgroup, QT query tiles per wave (a chunk = WAVES * QT * 16 queries), WPS = waves per SIMD the build is
 // held to (register budget 512 / WPS)
-template <int WAVES, int QT, int NS, int KB, int WPS>
+template <int WAVES, int QT, int NS, int KB, int WPS, bool QL2>
 __global__ __launch_bounds__(WAVES * 64, WPS) void attn_flash2_kernel(AttnArgs a, int chunks) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -429,19 +428,6 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void attn_flash2_kernel(AttnArgs a
     for (int s = 0; s < 2; ++s) qh[t][s] = *reinterpret_cast<const bf16x8_t*>(a.qkv_hi + (row0 + qc) * ld + qcol + 32 * s + 8 * g);
   }
 
-  if constexpr (TAPCLIP_FLASH2_PRESCALE != 0) {
-    // q <- q * log2(e), rounded to the operand type again (one more rounding of q: 2^-9 / 2^-12 relative per element, of
-    // the size of the one it already carries)
-#pragma unroll
-    for (int t = 0; t < QT; ++t)
-#pragma unroll
-      for (int sx = 0; sx < 2; ++sx) {
-        s16x8_t v = __builtin_bit_cast(s16x8_t, qh[t][sx]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (short)f2bf(bf2f((bf16_t)v[j]) * 1.44269504088896340736f);
-        qh[t][sx] = __builtin_bit_cast(bf16x8_t, v);
-      }
-  }
   // the Q fragments are consumed HERE as far as the compiler's wait-count pass can tell: left pending, their first use inside
   // the key loop gets an s_waitcnt vmcnt(0) that also drains the block DMAs issued behind them, in every iteration
 #pragma unroll
@@ -464,26 +450,29 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void attn_flash2_kernel(AttnArgs a
   const int kappa = 2 * (g & 1) + (qq >> 1);  // ((4 g + qq) >> 1) & 3
   ln.v_off0 = (4 * g + qq) * 128 + (((2 * pp) ^ kappa) << 4) + ((pp & 1) << 3);
 
-  if (nq == QT) flash2_run<WAVES, QT, NS, KB, QT>(a, smem, cx, ln, qh, tile0, row0, head, r);
-  else if (QT > 1 && nq == 1) flash2_run<WAVES, QT, NS, KB, 1>(a, smem, cx, ln, qh, tile0, row0, head, r);
-  else if (QT > 2 && nq == 2) flash2_run<WAVES, QT, NS, KB, (QT > 2 ? 2 : 0)>(a, smem, cx, ln, qh, tile0, row0, head, r);
-  else if (QT > 3 && nq == 3) flash2_run<WAVES, QT, NS, KB, (QT > 3 ? 3 : 0)>(a, smem, cx, ln, qh, tile0, row0, head, r);
-  else flash2_run<WAVES, QT, NS, KB, 0>(a, smem, cx, ln, qh, tile0, row0, head, r);
+  if (nq == QT) flash2_run<WAVES, QT, NS, KB, QT, QL2>(a, smem, cx, ln, qh, tile0, row0, head, r);
+#ifdef TAPCLIP_FLASH2_NQ_FULL  // (debug: a wave with any valid tile computes all of its tiles)
+  else if (nq > 0) flash2_run<WAVES, QT, NS, KB, QT, QL2>(a, smem, cx, ln, qh, tile0, row0, head, r);
+#endif
+  else if (QT > 1 && nq == 1) flash2_run<WAVES, QT, NS, KB, 1, QL2>(a, smem, cx, ln, qh, tile0, row0, head, r);
+  else if (QT > 2 && nq == 2) flash2_run<WAVES, QT, NS, KB, (QT > 2 ? 2 : 0), QL2>(a, smem, cx, ln, qh, tile0, row0, head, r);
+  else if (QT > 3 && nq == 3) flash2_run<WAVES, QT, NS, KB, (QT > 3 ? 3 : 0), QL2>(a, smem, cx, ln, qh, tile0, row0, head, r);
+  else flash2_run<WAVES, QT, NS, KB, 0, QL2>(a, smem, cx, ln, qh, tile0, row0, head, r);
 }
 
-template <int WAVES, int QT, int NS, int KB, int WPS>
+template <int WAVES, int QT, int NS, int KB, int WPS, bool QL2 = false>
 hipError_t launch_flash2_cfg(const AttnArgs& a, hipStream_t s) {
   constexpr int smem_bytes = NS * KB * 4096;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash2_kernel<WAVES, QT, NS, KB, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_flash2_kernel<WAVES, QT, NS, KB, WPS, QL2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   const int n_qt = (a.T + 15) / 16;
   const int chunks = (n_qt + WAVES * QT - 1) / (WAVES * QT);
   const int pairs8 = (a.n_seq * a.H + 7) / 8;
-  hipLaunchKernelGGL((attn_flash2_kernel<WAVES, QT, NS, KB, WPS>), dim3((unsigned)(pairs8 * 8 * chunks)), dim3(WAVES * 64), smem_bytes, s, a, chunks);
+  hipLaunchKernelGGL((attn_flash2_kernel<WAVES, QT, NS, KB, WPS, QL2>), dim3((unsigned)(pairs8 * 8 * chunks)), dim3(WAVES * 64), smem_bytes, s, a, chunks);
   return hipGetLastError();
 }
 
@@ -500,11 +489,16 @@ int flash2_cfg() {
 void flash2_set_cfg(int cfg) { g_flash2_cfg = cfg; }  // tools/attn_bench: switch geometries inside one process
 
 hipError_t launch_flash2(const AttnArgs& a, hipStream_t s) {
-  switch (flash2_cfg()) {
+  const int cfg = flash2_cfg();
+  if (a.q_log2) {  // (the geometries kept for A/B are built for plain q only)
+    return launch_flash2_cfg<4, 2, 3, 4, 3, true>(a, s);  // 250 us
+  }
+  switch (cfg) {
     // (measured at ViT-L/14@336, batch 128, same box, interleaved, every element of every output compared with the first
     //  kernel's: profiles/r05_attn_bench_*.log)
     case 122: return launch_flash2_cfg<12, 2, 6, 4, 3>(a, s);  // one 12-wave workgroup per CU, 2 chunks of 384 queries: 365-390 us
     case 822: return launch_flash2_cfg<8, 2, 6, 2, 4>(a, s);   // 8 waves, 32-key blocks (16 fewer score registers: 128 VGPRs), 3 chunks: 315 us
+    // (6 waves x 2 tiles, 3 - 5 stages, two workgroups per CU: 490 - 550 us; profiles/r05_attn_bench_six_waves.log)
     // (4 waves, 32-key blocks, four workgroups per CU -- <4, 2, 4, 2, 4> -- : 270 us with 5 spilled dwords; not kept)
     default: return launch_flash2_cfg<4, 2, 3, 4, 3>(a, s);    // 4 waves x 2 tiles (128 queries), 64-key blocks, three workgroups per CU: 258 us
   }

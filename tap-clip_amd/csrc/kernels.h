@@ -125,6 +125,9 @@ struct AttnArgs {
   // tied padding (tied.hip): ln(m) added to the score of the LAST key of every sequence, i.e. that key counts m times in
   // every softmax (0 = an ordinary key).  Not with causal, not in the flash kernel (T > 256).
   float last_key_bias = 0.f;
+  // q (and only q) carries log2(e) besides 1/sqrt(64): folded into Wq, bq at pack time by towers whose attention runs in
+  // attention_long.hip (image towers of more than 256 tokens, 16-bit operands).  Only that kernel takes it.
+  int32_t q_log2 = 0;
   // fp8 path: when out_q is set the output leaves as MXFP8 (e4m3 [n*T, D] + scales [D/64][out_m_pad][2]; a head's
   // 64 columns are one k-step of the out_proj GEMM) instead of bf16
   uint8_t* out_q = nullptr;
@@ -140,7 +143,7 @@ void flash2_set_cfg(int cfg);    // tools only
 // softmax(q K^T) V for ONE query row per sequence (the pooled token of a tower's last block): q [n_seq, D] (hi [+ lo]),
 // k / v taken from the q|k|v buffer [n_seq * T, 3 D] at columns D + 64 h / 2 D + 64 h, out [n_seq, D]
 hipError_t launch_attention_pooled(const bf16_t* q_hi, const bf16_t* q_lo, const bf16_t* qkv_hi, const bf16_t* qkv_lo, bf16_t* out_hi,
-                                   bf16_t* out_lo, int32_t n_seq, int32_t T, int32_t H, int32_t D, bool split, hipStream_t s);
+                                   bf16_t* out_lo, int32_t n_seq, int32_t T, int32_t H, int32_t D, bool split, hipStream_t s, bool q_log2 = false);
 
 // probs [n,H,T,T] -> mean over H -> [n,T,T]
 hipError_t launch_head_mean(const float* probs, int32_t n, int32_t H, int32_t T, float* out, hipStream_t s);

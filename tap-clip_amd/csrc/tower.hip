@@ -82,6 +82,7 @@ struct tapclip_tower {
   bool fp8 = false;       // TAPCLIP_PREC_FP8: block GEMMs on MXFP8 (image tower only)
   bool x24 = false;       // image tower, bf16 / IEEE-half modes: the residual stream of the blocks in 24-bit planes (layernorm.hip XF = 2)
   bool prune_last = true; // image tower: the last block computes K / V for every token but everything else for the CLS row only
+  bool q_log2 = false;    // image tower of more than 256 tokens, 16-bit operands: log2(e) folded into Wq, bq beside 1/sqrt(64) (AttnArgs::q_log2)
   bool ksplit = true;     // K-split the tiles of partial GEMM rounds over idle CUs (TAPCLIP_FLAG_KSPLIT)
   int tokens_vision = 0;  // G*G + 1
   int Kp = 0;             // padded 3*p*p
@@ -422,6 +423,7 @@ int run_blocks_fp8(tapclip_tower* t, int64_t n_seq, int tokens, const Workspace&
       a.out_q = w.ao_q; a.out_q_scale = w.ao_s; a.out_m_pad = w.m_pad;
       a.probs = nullptr;
       a.n_seq = (int)n_seq; a.T = tokens; a.H = H; a.D = D; a.causal = 0;
+      a.q_log2 = t->q_log2 ? 1 : 0;
       ProfScope ps(t, 3, s);
       HIP_TRY(launch_attention(a, false, s));
     }
@@ -490,6 +492,7 @@ int run_blocks(tapclip_tower* t, float* x, int64_t n_seq, int tokens, int causal
       a.probs = last ? probs_last : nullptr;
       a.n_seq = (int)n_seq; a.T = tokens; a.H = H; a.D = D; a.causal = causal;
       a.last_key_bias = last_key_bias;
+      a.q_log2 = t->q_log2 ? 1 : 0;
       ProfScope ps(t, 3, s);
       HIP_TRY(launch_attention(a, t->split, s));
       DBG_SYNC(4, s);
@@ -587,7 +590,7 @@ int run_last_block_pooled(tapclip_tower* t, float* x, int64_t n_seq, int tokens,
     return launch_gemm(a, epi, t->split, s);
   };
   HIP_TRY(small_gemm(EPI_BIAS_BF16, qa_hi, qa_lo, qa_ld, L.wqkv, L.bqkv, D, D, q_hi, q_lo));
-  HIP_TRY(launch_attention_pooled(q_hi, q_lo, w.qkv_hi, w.qkv_lo, ao_hi, ao_lo, (int)n_seq, tokens, H, D, t->split, s));
+  HIP_TRY(launch_attention_pooled(q_hi, q_lo, w.qkv_hi, w.qkv_lo, ao_hi, ao_lo, (int)n_seq, tokens, H, D, t->split, s, t->q_log2));
   HIP_TRY(small_gemm(EPI_BIAS_BF16, ao_hi, ao_lo, D, L.wo, L.bo, D, D, a_hi, a_lo));
   // the CLS rows of the residual stream -> fp32 [n, D], + out_proj's branch, LN2
   if (t->fp8) {
@@ -760,6 +763,12 @@ int tapclip_tower_create(const tapclip_tower_cfg* cfg, tapclip_tower_t** out) {
     t->x24 = !t->split && !t->fp8 && layernorm_x24_supports(cfg->width) && want_x24;
     static const bool no_prune = [] { const char* e = getenv("TAPCLIP_PRUNE_LAST"); return e && atoi(e) == 0; }();
     t->prune_last = !no_prune;
+    // the towers whose attention runs in attention_long.hip hand it base-2 scores: log2(e) goes into the q rows of in_proj at
+    // pack time (one rounding of the product, as for any weight), the kernel's exp2 then takes the MFMA output as it is
+    // (-3 % of the kernel).  TAPCLIP_Q_LOG2=0 at creation keeps natural-log scores (A/B); so does the A/B switch to the first
+    // flash kernel, which does not know the flag.
+    static const bool no_q_log2 = [] { const char* e = getenv("TAPCLIP_Q_LOG2"); return e && atoi(e) == 0; }();
+    t->q_log2 = t->tokens_vision > 256 && !t->split && !no_q_log2 && flash2_cfg() != 1;
     t->Kp = (3 * cfg->patch * cfg->patch + 63) / 64 * 64;
     for (const char* k : {"conv1.weight", "class_embedding", "positional_embedding", "ln_pre.weight", "ln_pre.bias",
                           "ln_post.weight", "ln_post.bias", "proj"})
@@ -826,7 +835,8 @@ int tapclip_tower_load_weight(tapclip_tower_t* t, const char* key_c, const float
       dst_t->lo = static_cast<bf16_t*>(l);
       return TAPCLIP_OK;
     };
-    const float qscale = 1.0f / sqrtf(64.0f);  // folded softmax scale; exact in bf16
+    // folded softmax scale (exact in bf16), times log2(e) where the attention kernel reads base-2 scores
+    const float qscale = (1.0f / sqrtf(64.0f)) * (t->q_log2 ? 1.44269504088896340736f : 1.0f);
     if (sub == "ln_1.weight") rc = vec(D, &L.ln1_g);
     else if (sub == "ln_1.bias") rc = vec(D, &L.ln1_b);
     else if (sub == "ln_2.weight") rc = vec(D, &L.ln2_g);

@@ -1,6 +1,8 @@
 // Check + interleaved timing of the long-sequence (T > 256) attention kernels at the ViT-L/14@336 shape (development tool; not
 // part of the library).  Build: make -C tools attn_bench.  Usage: tools/attn_bench [n_seq=128] [rounds=12] [cfg cfg ...]
-//   cfg: 1 = the first flash kernel (attention.hip attn_flash_kernel), WAVES * 10 + QT = a geometry of the second (42, 82, ...)
+//   cfg: 1 = the first flash kernel (attention.hip attn_flash_kernel), 0 = the shipped geometry of attention_long.hip, 122 / 822 /
+//   62x = its other geometries; + 10000 = the same with q in log2 units (AttnArgs::q_log2: a second q|k|v whose q columns are
+//   the SAME fp32 values times log2(e), rounded once -- what a tower with log2(e) folded into Wq produces)
 // The check: softmax(q k^T) v in double on the host for a few (sequence, head) pairs, from the same 16-bit q|k|v.
 #include <hip/hip_runtime.h>
 
@@ -40,7 +42,7 @@ static float h2f(uint16_t b) {
 #endif
 
 // q|k|v rows: approximately normal entries (sum of four uniforms), written as the library's 16-bit operand type
-__global__ void fill_kernel(uint16_t* p, size_t n, float scale, uint32_t seed) {
+__global__ void fill_kernel(uint16_t* p, size_t n, float scale, uint32_t seed, int D, float qmul) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
@@ -50,7 +52,8 @@ __global__ void fill_kernel(uint16_t* p, size_t n, float scale, uint32_t seed) {
       s ^= s >> 33; s *= 0xff51afd7ed558ccdull; s ^= s >> 33; s *= 0xc4ceb9fe1a85ec53ull; s ^= s >> 29;
       acc += (float)(s & 0xFFFFFF) / 16777216.0f - 0.5f;
     }
-    const float v = acc * 1.7320508f * scale;  // variance scale^2
+    float v = acc * 1.7320508f * scale;  // variance scale^2
+    if ((int)(i % (size_t)(3 * D)) < D) v *= qmul;
 #ifdef TAPCLIP_FP16
     _Float16 h = (_Float16)v;
     uint16_t b;
@@ -74,10 +77,15 @@ int main(int argc, char** argv) {
   const int T = getenv("ATTN_BENCH_T") ? atoi(getenv("ATTN_BENCH_T")) : 577, H = 16, D = 1024;
   const float scale = getenv("ATTN_BENCH_SCALE") ? (float)atof(getenv("ATTN_BENCH_SCALE")) : 0.6f;  // q.k sigma = 64^0.5 scale^2 = 2.9
   const size_t rows = (size_t)n_seq * T;
-  uint16_t *qkv, *out;
+  uint16_t *qkv, *qkv_l2 = nullptr, *out;
   CK(hipMalloc(&qkv, rows * 3 * D * 2));
   CK(hipMalloc(&out, rows * D * 2));
-  hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, qkv, rows * 3 * D, scale, 12345u);
+  hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, qkv, rows * 3 * D, scale, 12345u, D, 1.0f);
+  for (int c : cfgs)
+    if (c >= 10000 && c < 20000 && !qkv_l2) {
+      CK(hipMalloc(&qkv_l2, rows * 3 * D * 2));
+      hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, qkv_l2, rows * 3 * D, scale, 12345u, D, 1.44269504088896340736f);
+    }
   CK(hipDeviceSynchronize());
   hipStream_t s;
   CK(hipStreamCreate(&s));
@@ -88,9 +96,12 @@ int main(int argc, char** argv) {
   // ---- check: pairs (first, middle, last sequence) x (heads 0, 7, 15), every query row
   const int seqs[3] = {0, n_seq / 2, n_seq - 1}, heads[3] = {0, 7, 15};
   std::vector<uint16_t> hq((size_t)T * 3 * D), ho((size_t)T * D);
-  std::vector<double> ref((size_t)9 * T * 64);
+  // (the log2-unit configurations are checked against the softmax of THEIR q / log2(e): the rounding of q * log2(e) is an input's
+  //  rounding -- a weight's, in a tower -- not the kernel's)
+  auto host_ref = [&](const uint16_t* src, double qdiv, std::vector<double>& ref) {
+  ref.assign((size_t)9 * T * 64, 0.0);
   for (int si = 0; si < 3; ++si) {
-    CK(hipMemcpy(hq.data(), qkv + (size_t)seqs[si] * T * 3 * D, hq.size() * 2, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hq.data(), src + (size_t)seqs[si] * T * 3 * D, hq.size() * 2, hipMemcpyDeviceToHost));
     for (int hi = 0; hi < 3; ++hi) {
       const int h = heads[hi];
       std::vector<double> p(T);
@@ -99,6 +110,7 @@ int main(int argc, char** argv) {
         for (int k = 0; k < T; ++k) {
           double sc = 0;
           for (int d = 0; d < 64; ++d) sc += (double)h2f(hq[(size_t)q * 3 * D + h * 64 + d]) * (double)h2f(hq[(size_t)k * 3 * D + D + h * 64 + d]);
+          sc /= qdiv;
           p[k] = sc;
           mx = std::max(mx, sc);
         }
@@ -112,25 +124,62 @@ int main(int argc, char** argv) {
       }
     }
   }
+  };
+  std::vector<double> ref_nat, ref_l2, ref_b2;
+  host_ref(qkv, 1.0, ref_nat);
+  for (int c : cfgs)
+    if (c >= 20000 && ref_b2.empty()) host_ref(qkv, 1.44269504088896340736, ref_b2);
+  if (qkv_l2) host_ref(qkv_l2, 1.44269504088896340736, ref_l2);
+  auto select = [&](int cfg) {
+    flash2_set_cfg(cfg % 10000);
+    a.qkv_hi = (cfg >= 10000 && cfg < 20000) ? qkv_l2 : qkv;  // (+ 20000: the log2 kernel on the natural buffer = a base-2 softmax)
+    a.q_log2 = cfg >= 10000 ? 1 : 0;
+  };
   bool ok = true;
   for (int cfg : cfgs) {
-    flash2_set_cfg(cfg);
+    select(cfg);
+    const std::vector<double>& ref = cfg >= 20000 ? ref_b2 : cfg >= 10000 ? ref_l2 : ref_nat;
     CK(hipMemsetAsync(out, 0xFF, rows * D * 2, s));  // NaN patterns: an unwritten element shows
     CK(launch_attention(a, false, s));
     CK(hipStreamSynchronize(s));
     double max_err = 0, sum_sq = 0, ref_sq = 0;
+    struct Worst { double e; int si, hi, q; };
+    std::vector<Worst> worst;
     for (int si = 0; si < 3; ++si) {
       CK(hipMemcpy(ho.data(), out + (size_t)seqs[si] * T * D, ho.size() * 2, hipMemcpyDeviceToHost));
       for (int hi = 0; hi < 3; ++hi)
-        for (int q = 0; q < T; ++q)
+        for (int q = 0; q < T; ++q) {
+          double row = 0;
           for (int d = 0; d < 64; ++d) {
             const double g = h2f(ho[(size_t)q * D + heads[hi] * 64 + d]), r = ref[((size_t)(si * 3 + hi) * T + q) * 64 + d];
             const double e = std::fabs(g - r);
             if (!(e == e)) max_err = 1e30;
             max_err = std::max(max_err, e);
+            row = std::max(row, e == e ? e : 1e30);
             sum_sq += e * e;
             ref_sq += r * r;
           }
+          worst.push_back({row, si, hi, q});
+        }
+    }
+    if (getenv("ATTN_BENCH_WORST")) {  // the rows furthest off, with the per-64-key-block score maxima of each (host, double)
+      std::sort(worst.begin(), worst.end(), [](const Worst& x, const Worst& y) { return x.e > y.e; });
+      const uint16_t* src = a.qkv_hi;
+      for (int w = 0; w < 6; ++w) {
+        const Worst& ww = worst[w];
+        CK(hipMemcpy(hq.data(), src + (size_t)seqs[ww.si] * T * 3 * D, hq.size() * 2, hipMemcpyDeviceToHost));
+        printf("   worst: seq %d head %d token %d err %.3e  block maxima:", seqs[ww.si], heads[ww.hi], ww.q, ww.e);
+        for (int kb = 0; kb * 64 < T; ++kb) {
+          double bm = -1e300;
+          for (int k = kb * 64; k < T && k < kb * 64 + 64; ++k) {
+            double sc = 0;
+            for (int d = 0; d < 64; ++d) sc += (double)h2f(hq[(size_t)ww.q * 3 * D + heads[ww.hi] * 64 + d]) * (double)h2f(hq[(size_t)k * 3 * D + D + heads[ww.hi] * 64 + d]);
+            bm = std::max(bm, sc);
+          }
+          printf(" %.1f", bm);
+        }
+        printf("\n");
+      }
     }
     // every element of the whole output written and finite
     std::vector<uint16_t> all(rows * D);
@@ -150,7 +199,7 @@ int main(int argc, char** argv) {
     double max_diff = 0;
     size_t far = 0;
     if (first.empty()) first = all;
-    else
+    else if (cfg < 20000)
       for (size_t i = 0; i < all.size(); ++i) {
         const double dd = std::fabs((double)h2f(all[i]) - (double)h2f(first[i]));
         if (dd > max_diff) max_diff = dd;
@@ -159,7 +208,7 @@ int main(int argc, char** argv) {
           ++far;
         }
       }
-    printf("cfg %3d: check vs fp64 host softmax: max abs err %.3e  rel-L2 %.3e  non-finite/unwritten %zu | vs first cfg: max diff %.3e, %zu beyond 0.03\n", cfg,
+    printf("cfg %5d: check vs fp64 host softmax: max abs err %.3e  rel-L2 %.3e  non-finite/unwritten %zu | vs first cfg: max diff %.3e, %zu beyond 0.03\n", cfg,
            max_err, rel, bad, max_diff, far);
     if (rel > 8e-3 || bad || far) ok = false;
   }
@@ -169,12 +218,12 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   std::vector<std::vector<float>> t(cfgs.size());
-  flash2_set_cfg(cfgs[0]);
+  select(cfgs[0]);
   for (int w = 0; w < 200; ++w) CK(launch_attention(a, false, s));  // clocks settle
   CK(hipStreamSynchronize(s));
   for (int round = 0; round < rounds; ++round)
     for (size_t c = 0; c < cfgs.size(); ++c) {
-      flash2_set_cfg(cfgs[c]);
+      select(cfgs[c]);
       CK(launch_attention(a, false, s));
       CK(hipEventRecord(e0, s));
       for (int i = 0; i < 4; ++i) CK(launch_attention(a, false, s));
@@ -188,7 +237,7 @@ int main(int argc, char** argv) {
   for (size_t c = 0; c < cfgs.size(); ++c) {
     std::sort(t[c].begin(), t[c].end());
     const double med = t[c][t[c].size() / 2], mn = t[c][0];
-    printf("cfg %3d  n%d T%d H%d: median %8.1f us %7.1f TFLOP/s   min %8.1f us\n", cfgs[c], n_seq, T, H, 1e3 * med, fl / (med * 1e-3) / 1e12, 1e3 * mn);
+    printf("cfg %5d  n%d T%d H%d: median %8.1f us %7.1f TFLOP/s   min %8.1f us\n", cfgs[c], n_seq, T, H, 1e3 * med, fl / (med * 1e-3) / 1e12, 1e3 * mn);
   }
   printf(ok ? "CHECK OK\n" : "CHECK FAILED\n");
   return ok ? 0 : 1;
