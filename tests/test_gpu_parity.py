@@ -149,10 +149,13 @@ def test_gemm_identity_asymmetric(eng):
 
 
 # ---- one residual block at the real widths vs torch.nn.MultiheadAttention goldens ----------------
-def _one_layer_tower(eng, d, heads, mlp, seed, precision):
+def _one_layer_tower(eng, d, heads, mlp, seed, precision, q_gain=1.0):
     cfg = configs.ClipDims("blk", 64, 224, 16, configs.TowerDims(d, 1, heads, mlp), configs.TowerDims(d, 1, heads, mlp), vocab=16, ctx=8)
     sd = {}
     synth._tower(sd, "transformer.", d, 1, mlp, seed=seed)
+    if q_gain != 1.0:  # wider scores: q.k / 8 has sigma = q_gain on these weights
+        sd["transformer.resblocks.0.attn.in_proj_weight"][:d] *= q_gain
+        sd["transformer.resblocks.0.attn.in_proj_bias"][:d] *= q_gain
     sd["token_embedding.weight"] = torch.zeros(16, d)
     sd["positional_embedding"] = torch.zeros(8, d)
     sd["ln_final.weight"] = torch.ones(d)
@@ -255,6 +258,65 @@ def test_long_sequence_attention_token_counts(eng, precision, size):
     assert torch.equal(a, b), "same input twice must be bit-identical"
     assert bool(torch.isfinite(a).all())
     assert rel_max(a, ref) < (TOL if precision == "fp16" else TOL_BF16)
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+@pytest.mark.parametrize("T", [530, 576, 577, 641])
+def test_long_sequence_attention_wide_scores(eng, precision, T):
+    """EVERY row of one block through the T > 256 kernel with scores of sigma 6 (maxima near 20, softmax rows that rescale
+    by e^10 from one key block to the next), at token counts whose last query chunk leaves waves with ONE query tile, with
+    and without a partial last key block.  This is the shape that showed the round-5 hazard (profiles/r05_flash2_asm_hazard.txt:
+    an asm statement read the last key tile's scores before their MFMA had landed -- hipcc does not pad asm operands -- so a
+    block maximum missed its largest score: P beyond the half range, NaN rows; far-off rows in bf16).  With that asm statement
+    put back, [530-bf16] and [576-bf16] fail (profiles/r05_asm_hazard_regression_tests.log).  "fp16" on a text-kind tower is the
+    split-bf16 mode: the first flash kernel of attention.hip (measured 2e-5); "bf16" is the LDS-DMA kernel (measured 9.9e-3: the
+    2^-9 rounding of q and k on sums of sigma 6)."""
+    tower, sd = _one_layer_tower(eng, 256, 4, 512, 23, precision, q_gain=6.0)
+    x = synth.normal([3, T, 256], 40 + T, "wide.x")
+    a = tower.forward(x.to(DEV))["hidden"].cpu()
+    b = tower.forward(x.to(DEV))["hidden"].cpu()
+    with torch.no_grad():
+        y, _ = clip_ref.block_forward(x, sd, "transformer.resblocks.0.", 4)
+    _report(f"wide-score block T={T} {precision}", a, y)
+    assert bool(torch.isfinite(a).all()), "non-finite rows"
+    assert torch.equal(a, b), "same input twice must be bit-identical"
+    row_err = (a - y).abs().amax(dim=-1) / y.abs().max()
+    worst = int(row_err.argmax())
+    assert float(row_err.max()) < (TOL if precision == "fp16" else 3e-2), f"row {worst % T} of sequence {worst // T}: {float(row_err.max()):.3e}"
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_base2_scores_tower_wide_scores(eng, precision):
+    """The same hazard shape through the path that folds log2(e) into Wq (image towers of more than 256 tokens: base-2 scores,
+    AttnArgs::q_log2): two blocks at 577 tokens with every row computed, so a bad row of block 1 is a key / value of block 2's
+    CLS query; q gains of 6 in both blocks.  Against the fp32 oracle, with the CLS-only last block and without (measured 8.4e-4 in
+    IEEE half, 6.9e-3 in bf16; with the asm maximum put back the half build returns NaN: r05_asm_hazard_regression_tests.log)."""
+    d, heads, mlp, size = 256, 4, 512, 336
+    cfg = configs.ClipDims("wide336", 64, size, 14, configs.TowerDims(d, 2, heads, mlp), configs.TowerDims(128, 1, 2, 256), vocab=16, ctx=8)
+    ocfg = clip_ref.ClipDims("wide336", 64, size, 14, clip_ref.TowerDims(d, 2, heads, mlp), clip_ref.TowerDims(128, 1, 2, 256), vocab=16, ctx=8)
+    tokens = (size // 14) ** 2 + 1
+    sd = {}
+    synth._tower(sd, "visual.transformer.", d, 2, mlp, seed=22)
+    for li in range(2):
+        sd[f"visual.transformer.resblocks.{li}.attn.in_proj_weight"][:d] *= 6.0
+        sd[f"visual.transformer.resblocks.{li}.attn.in_proj_bias"][:d] *= 6.0
+    g = torch.Generator().manual_seed(77)
+    sd["visual.conv1.weight"] = torch.randn(d, 3, 14, 14, generator=g) * 0.03
+    sd["visual.class_embedding"] = torch.randn(d, generator=g) * 0.3
+    sd["visual.positional_embedding"] = torch.randn(tokens, d, generator=g) * 0.3
+    for k in ("ln_pre", "ln_post"):
+        sd[f"visual.{k}.weight"] = 1.0 + 0.1 * torch.randn(d, generator=g)
+        sd[f"visual.{k}.bias"] = 0.05 * torch.randn(d, generator=g)
+    sd["visual.proj"] = torch.randn(d, 64, generator=g) * d ** -0.5
+    images = synth.make_images(4, cfg, 32)
+    with torch.no_grad():
+        ref = clip_ref.encode_image(images, sd, ocfg)
+    tol = 3e-3 if precision == "fp16" else 3e-2  # (the rounding of q and k at this score width, not BASELINE's 1e-3)
+    for prune in (False, True):
+        emb = eng.VisionTower(cfg, sd, DEV, precision, prune_last_block=prune).encode_image(images.to(DEV)).cpu()
+        _report(f"base-2 scores, wide, 2 blocks x {tokens} tokens {precision} prune={prune}", emb, ref)
+        assert bool(torch.isfinite(emb).all())
+        assert rel_max(emb, ref) < tol
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
