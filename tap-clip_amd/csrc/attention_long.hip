@@ -3,12 +3,14 @@
 // (kernels.h AttnArgs; the scaled-dot-product step inside nn.MultiheadAttention of open_clip's
 // ResidualAttentionBlock, reference call site models/clip_wrapper.py:46-47).
 //
-// Its own translation unit because it is compiled WITHOUT packed-fp32 VALU ops (common.h TAPCLIP_TU_NO_PK_F32): with the
-// rescale of the O accumulators as hipcc forms it -- v_pk_mul_f32 v[a:a+1], v[a:a+1], v[s:s+1] op_sel_hi:[1,0] -- this kernel
-// returned NaN or far-off rows for 15-25 of the 1.18 M query rows of a launch, different rows in every run, with its own
-// other waves' LDS-fed MFMAs running on the same CU; with plain v_mul_f32 it does not (tools/attn_bench checks every element of
-// every configuration against the first kernel's output; profiles/r05_flash2_packed_rescale.txt).  The erratum of round 2 again
-// (DESIGN.md), on an encoding the round-2 probe -- a neighbour KERNEL on a second stream -- never saw fail.
+// Its own translation unit for two build switches (csrc/Makefile):
+//  * -fno-honor-nans: the score maxima are plain fmaxf, which hipcc then folds into v_max3_f32 without canonicalising the MFMA
+//    outputs first (flash2_tile_max below, and why no asm statement reads an MFMA result any more).
+//  * no packed-fp32 VALU ops (common.h TAPCLIP_TU_NO_PK_F32), like every kernel file that runs VALU arithmetic beside LDS-fed MFMAs
+//    (the round-2 erratum: op_sel = [0,1,..] encodings, which hipcc may form from any packed multiply).  For a while in round 5
+//    this file was thought to show a SECOND erratum -- NaN / far-off rows in 15-25 of 1.18 M query rows per launch with
+//    v_pk_mul_f32 .. op_sel_hi:[1,0] rescaling the O accumulators.  It did not: those rows came from the asm maximum reading MFMA
+//    results too early (profiles/r05_flash2_asm_hazard.txt); the build that keeps packed ops is clean now and no faster.
 #include <cstdlib>
 
 #ifndef TAPCLIP_TU_NO_NANS

@@ -107,12 +107,15 @@ __device__ __forceinline__ uint32_t mx8_pack4(float a, float b, float c, float d
   v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);   // bytes 2, 3
   return (uint32_t)v;
 }
-// max(m, |a|, |b|) in one op (fmaxf / fabsf on packed results no longer fuse into v_max3_f32 by themselves)
+// max(m, |a|, |b|) in one op (fmaxf / fabsf on packed results no longer fuse into v_max3_f32 by themselves).  ONLY for values a
+// VALU instruction produced: hipcc does not pad an asm statement for the MFMA -> VALU read hazard (gfx950 has no interlock; see
+// attention_long.hip flash2_tile_max and profiles/r05_flash2_asm_hazard.txt), so raw MFMA results take amax3_visible.
 __device__ __forceinline__ float amax3_raw(float m, float a, float b) {
   float d;
   asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(d) : "v"(m), "v"(a), "v"(b));
   return d;
 }
+__device__ __forceinline__ float amax3_visible(float m, float a, float b) { return fmaxf(m, fmaxf(__builtin_fabsf(a), __builtin_fabsf(b))); }
 // the same on two pairs (the scale multiply as v_pk_mul_f32)
 typedef float f32x2_mx_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t mx8_pack4(f32x2_mx_t ab, f32x2_mx_t cd, float inv) {
@@ -204,11 +207,12 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 typedef float f32x2_pk_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2_pk_t gelu_poly2(f32x2_pk_t x) {
   f32x2_pk_t t, r;
-  // raw v_min / v_max: fminf / fmaxf would first canonicalise the MFMA output (one more VALU op per value)
-  asm("v_min_f32_e64 %0, |%1|, %2" : "=v"(t[0]) : "v"(x[0]), "v"(4.5f));
-  asm("v_min_f32_e64 %0, |%1|, %2" : "=v"(t[1]) : "v"(x[1]), "v"(4.5f));
-  asm("v_max_f32_e32 %0, 0, %1" : "=v"(r[0]) : "v"(x[0]));
-  asm("v_max_f32_e32 %0, 0, %1" : "=v"(r[1]) : "v"(x[1]));
+  // (plain fminf / fmaxf: they canonicalise their operand first, one more VALU op per value -- the round-4 measurement of this
+  // form used raw v_min / v_max in asm statements, which hipcc does not pad for the MFMA -> VALU read hazard: not kept)
+  t[0] = fminf(__builtin_fabsf(x[0]), 4.5f);
+  t[1] = fminf(__builtin_fabsf(x[1]), 4.5f);
+  r[0] = fmaxf(x[0], 0.f);
+  r[1] = fmaxf(x[1], 0.f);
   const f32x2_pk_t u = __builtin_elementwise_fma(t, f32x2_pk_t{0.44444445f, 0.44444445f}, f32x2_pk_t{-1.0f, -1.0f});
   constexpr float C[11] = {-2.749713324e-02f, 1.330395043e-01f, -2.465924025e-01f, 1.472157985e-01f, 2.029682845e-01f, -4.347813427e-01f,
                            2.049071938e-01f,  1.763149798e-01f, -1.763803661e-01f, -2.178246900e-02f, 4.258675873e-02f};

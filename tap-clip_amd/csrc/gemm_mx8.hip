@@ -328,7 +328,7 @@ __global__ __launch_bounds__(512) void gemm_mx8_kernel(Mx8GemmArgs g) {
           for (int e = 0; e < 16; ++e) {
             const f32x2_pk_t x = {acc[e >> 3][i][(2 * e) & 15], acc[e >> 3][i][(2 * e + 1) & 15]};
             y[e] = ACT == 0 ? gelu_erf_fast2(x) : ACT == 1 ? gelu_quick_fast2(x) : x;
-            amax = amax3_raw(amax, y[e][0], y[e][1]);
+            amax = ACT == 2 ? amax3_visible(amax, y[e][0], y[e][1]) : amax3_raw(amax, y[e][0], y[e][1]);  // (ACT 2: y is the MFMA's own register)
           }
           const uint32_t byte = mx8_scale_byte(amax);
           const float inv = mx8_inv_scale(byte);

@@ -235,10 +235,9 @@ def test_no_unsafe_packed_fp32_encodings(variant, tmp_path):
     # them that way costs 20-40 % of the first two (round 3) and 10 % of the split-bf16 text tower for the third (round 4).
     csrc = os.path.dirname(path)
     sfx = ".o" if variant == "bf16" else ".f16.o"
-    # (attention_long, round 5: with v_pk_mul_f32 v[a:a+1], v[a:a+1], v[s:s+1] op_sel_hi:[1,0] -- the rescale of its MFMA
-    # accumulators as hipcc forms it -- the kernel returned NaN / far-off rows in 15-25 of 1.18 M query rows per launch, other
-    # rows every run; with plain v_mul_f32 none: profiles/r05_flash2_packed_rescale.txt.  That encoding is NOT in _PK_F32: the
-    # GEMM epilogues carry it and have been bit-stable since round 1.)
+    # (attention_long, round 5: built this way like every file whose VALU arithmetic runs beside LDS-fed MFMAs.  The NaN / far-off
+    # rows first blamed on its v_pk_mul_f32 .. op_sel_hi:[1,0] -- profiles/r05_flash2_packed_rescale.txt -- were an asm statement
+    # reading MFMA results unpadded: profiles/r05_flash2_asm_hazard.txt.  That encoding is not in _PK_F32, and need not be.)
     for unit in ("layernorm", "tied", "elementwise", "backward", "preprocess", "gemm_skinny", "mx8", "attention_long"):
         obj = os.path.join(csrc, unit + sfx)
         assert os.path.exists(obj), f"{obj} missing: build with make -C tap-clip_amd/csrc"

@@ -195,11 +195,14 @@ int main(int argc, char** argv) {
     const double rel = std::sqrt(sum_sq / ref_sq);
     // the whole output against the first configuration's (both are deterministic: differences beyond the 16-bit rounding of
     // two summation orders mean corrupted operands somewhere the nine checked pairs do not look)
-    static std::vector<uint16_t> first;
+    // (a log2-unit configuration reads a DIFFERENTLY rounded q: it is compared with the first configuration of its own kind --
+    //  at wide scores two roundings of q move peaky softmax rows by more than 0.03)
+    static std::vector<uint16_t> first_of[3];
+    std::vector<uint16_t>& first = first_of[cfg >= 20000 ? 2 : cfg >= 10000 ? 1 : 0];
     double max_diff = 0;
     size_t far = 0;
     if (first.empty()) first = all;
-    else if (cfg < 20000)
+    else
       for (size_t i = 0; i < all.size(); ++i) {
         const double dd = std::fabs((double)h2f(all[i]) - (double)h2f(first[i]));
         if (dd > max_diff) max_diff = dd;
@@ -208,7 +211,7 @@ int main(int argc, char** argv) {
           ++far;
         }
       }
-    printf("cfg %5d: check vs fp64 host softmax: max abs err %.3e  rel-L2 %.3e  non-finite/unwritten %zu | vs first cfg: max diff %.3e, %zu beyond 0.03\n", cfg,
+    printf("cfg %5d: check vs fp64 host softmax: max abs err %.3e  rel-L2 %.3e  non-finite/unwritten %zu | vs first cfg of its kind: max diff %.3e, %zu beyond 0.03\n", cfg,
            max_err, rel, bad, max_diff, far);
     if (rel > 8e-3 || bad || far) ok = false;
   }
