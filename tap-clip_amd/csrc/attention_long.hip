@@ -500,7 +500,9 @@ hipError_t launch_flash2(const AttnArgs& a, hipStream_t s) {
     //  kernel's: profiles/r05_attn_bench_*.log)
     case 122: return launch_flash2_cfg<12, 2, 6, 4, 3>(a, s);  // one 12-wave workgroup per CU, 2 chunks of 384 queries: 365-390 us
     case 822: return launch_flash2_cfg<8, 2, 6, 2, 4>(a, s);   // 8 waves, 32-key blocks (16 fewer score registers: 128 VGPRs), 3 chunks: 315 us
-    // (6 waves x 2 tiles, 3 - 5 stages, two workgroups per CU: 490 - 550 us; profiles/r05_attn_bench_six_waves.log)
+    // (6 waves x 2 tiles, 3 - 5 stages: 490 - 550 us -- 2 + 2 + 1 + 1 waves per SIMD twice do not fit three per SIMD, so ONE workgroup
+    //  per CU; profiles/r05_attn_bench_six_waves.log.  5 waves x 2 tiles, 4 chunks of 160 queries, 3 - 5 stages: the same time as
+    //  this geometry to 0.1 % at 257 / 577 / 1 025 tokens)
     // (4 waves, 32-key blocks, four workgroups per CU -- <4, 2, 4, 2, 4> -- : 270 us with 5 spilled dwords; not kept)
     default: return launch_flash2_cfg<4, 2, 3, 4, 3>(a, s);    // 4 waves x 2 tiles (128 queries), 64-key blocks, three workgroups per CU: 258 us
   }
