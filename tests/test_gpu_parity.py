@@ -286,12 +286,13 @@ def test_long_sequence_attention_wide_scores(eng, precision, T):
 
 
 @pytest.mark.parametrize("precision", ["fp16", "bf16"])
-def test_base2_scores_tower_wide_scores(eng, precision):
+@pytest.mark.parametrize("size", [224, 322, 336])
+def test_base2_scores_tower_wide_scores(eng, precision, size):
     """The same hazard shape through the path that folds log2(e) into Wq (image towers of more than 256 tokens: base-2 scores,
-    AttnArgs::q_log2): two blocks at 577 tokens with every row computed, so a bad row of block 1 is a key / value of block 2's
-    CLS query; q gains of 6 in both blocks.  Against the fp32 oracle, with the CLS-only last block and without (measured 8.4e-4 in
-    IEEE half, 6.9e-3 in bf16; with the asm maximum put back the half build returns NaN: r05_asm_hazard_regression_tests.log)."""
-    d, heads, mlp, size = 256, 4, 512, 336
+    AttnArgs::q_log2): two blocks at 257 / 530 / 577 tokens with every row computed, so a bad row of block 1 is a key / value of block 2's
+    CLS query; q gains of 6 in both blocks.  Against the fp32 oracle, with the CLS-only last block and without (measured 0.8 - 1.6e-3 in
+    IEEE half, 6.0 - 8.5e-3 in bf16; with the asm maximum put back the half build returns NaN: r05_asm_hazard_regression_tests.log)."""
+    d, heads, mlp = 256, 4, 512
     cfg = configs.ClipDims("wide336", 64, size, 14, configs.TowerDims(d, 2, heads, mlp), configs.TowerDims(128, 1, 2, 256), vocab=16, ctx=8)
     ocfg = clip_ref.ClipDims("wide336", 64, size, 14, clip_ref.TowerDims(d, 2, heads, mlp), clip_ref.TowerDims(128, 1, 2, 256), vocab=16, ctx=8)
     tokens = (size // 14) ** 2 + 1
