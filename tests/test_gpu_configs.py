@@ -786,8 +786,9 @@ def test_image_tower_is_bit_stable_beside_a_busy_second_stream(eng, name, batch,
 def test_long_sequence_tower_is_bit_stable_beside_a_busy_second_stream(eng, precision):
     """The same for the 577-token geometry (ViT-L/14@336 widths, 2 blocks, batch 16): the LDS-DMA attention kernel of round 5
     (csrc/attention_long.hip) keeps hand-counted vmcnt / lgkmcnt queues and runs VALU arithmetic on MFMA accumulators beside its
-    own LDS-fed MFMAs -- with packed-fp32 ops in it 15-25 of 1.18 M rows came out wrong per launch, other rows every run
-    (profiles/r05_flash2_packed_rescale.txt).  Every run beside a busy neighbour must equal the solo run bit for bit."""
+    own LDS-fed MFMAs; a timing-dependent fault of an earlier build (an asm statement that read MFMA results unpadded:
+    profiles/r05_flash2_asm_hazard.txt) showed as other wrong rows every run.  Every run beside a busy neighbour must equal the
+    solo run bit for bit."""
     cfg = configs.ClipDims("L14-336-2blocks", 768, 336, 14, configs.TowerDims(1024, 2, 16, 4096), configs.TowerDims(512, 2, 8, 2048), vocab=512)
     sd = synth.make_state_dict(cfg, seed=2)
     images = synth.make_images(16, cfg, 0).to(DEV)
