@@ -67,3 +67,25 @@ def test_hot_kernels_use_no_scratch():
             pat2, limit = SMALL_SPILL[src]
             lean = {k: v for k, v in usage.items() if re.search(pat2, k)}
             assert lean and all(v <= limit for v in lean.values()), f"{src}: {lean}"
+
+
+def test_no_asm_statement_computes_on_vector_registers():
+    """hipcc pads its OWN instructions for the MFMA -> VALU read hazard (gfx950 has no interlock: an 8-pass MFMA's result may be read
+    11 wait states after its issue) and does not look at the operands of an asm statement.  An asm `v_max3_f32` chain over score
+    registers read stale values four instructions after their MFMA (profiles/r05_flash2_asm_hazard.txt).  So the kernel sources may
+    hold VALU instructions in asm statements only where listed here, each with the reason its operands cannot be MFMA results."""
+    allowed = {
+        # max (m, |a|, |b|) over values the GELU's own VALU ops produced (gemm_mx8.hip: the identity epilogue takes amax3_visible)
+        ("common.h", "v_max3_f32"),
+    }
+    found = set()
+    for name in sorted(os.listdir(CSRC)):
+        if not name.endswith((".hip", ".h")):
+            continue
+        text = open(os.path.join(CSRC, name)).read()
+        for m in re.finditer(r"\basm\s*(?:volatile)?\s*\(((?:[^()]|\((?:[^()]|\([^()]*\))*\))*)\)", text):
+            for op in re.findall(r"\b(v_[a-z0-9_]+)", m.group(1)):
+                if not op.startswith(("v_mfma",)):
+                    found.add((name, op))
+    assert found <= allowed, f"VALU instructions inside asm statements: {sorted(found - allowed)} (see this test's docstring)"
+    assert ("common.h", "v_max3_f32") in found, "the scan no longer sees the one statement it should"
